@@ -1,0 +1,188 @@
+"""Deterministic synthetic inputs for the Dreamer world-model training step.
+
+Everything here is derived from numpy ``Generator(PCG64(seed))`` streams so that the golden
+generator (which imports the reference in the build container), the parity tests and ``bench.py``
+(which run on the GPU box, where the reference does not exist) all see bit-identical weights,
+replay contents, batches and noise without any of them having to be stored.
+
+Shapes follow SURVEY.md section 8: time-major ``(time, batch, feature)`` fp32.
+Parameter names/shapes follow the reference ``state_dict`` (``src/models.py:149-167`` for the RSSM,
+``src/utils.py:368-404`` ``build_mlp`` for the dense heads).
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+
+@dataclasses.dataclass(frozen=True)
+class Dims:
+    """Problem dimensions (names as in SURVEY.md section 8)."""
+
+    B: int = 50      # batch_size            (conf/config.yaml:22)
+    L: int = 50      # seq_len / chunk       (conf/config.yaml:23)
+    H: int = 15      # planning_horizon      (conf/config.yaml:31)
+    Be: int = 200    # belief_size
+    S: int = 30      # state_size
+    Hd: int = 200    # hidden_size
+    E: int = 1024    # embedding_size
+    A: int = 1       # action_size (Pendulum 1)
+    O: int = 3       # observation_size (Pendulum 3, state observations)
+    n_entropy: int = 100  # SampleDist samples (src/models.py:681)
+
+    @property
+    def T(self) -> int:
+        return self.L - 1
+
+    @property
+    def N(self) -> int:
+        return self.T * self.B
+
+    @property
+    def Hm(self) -> int:  # H' = number of imagination steps actually run (src/dreamer.py:213)
+        return self.H - 1
+
+    @property
+    def transitions_per_step(self) -> int:
+        """GRU-cell applications per train_step: (L-1)*B*H."""
+        return self.T * self.B * self.H
+
+
+CONFIG1 = Dims(B=50, L=50, H=15, Be=32, S=30, Hd=32, E=1024, A=1, O=3)     # BASELINE.json configs[0]
+CONFIG2 = Dims()                                                           # BASELINE.json configs[1]
+TINY = Dims(B=3, L=5, H=4, Be=24, S=6, Hd=20, E=40, A=2, O=5, n_entropy=100)
+SMALL = Dims(B=7, L=9, H=6, Be=48, S=10, Hd=36, E=72, A=3, O=4, n_entropy=100)
+
+DENSE_LAYERS = 4  # DenseModel / ActorModel n_layers (src/models.py:378,482)
+
+
+def _mlp_shapes(prefix: str, sizes: List[int]) -> List[Tuple[str, Tuple[int, ...]]]:
+    """``build_mlp`` puts Linear layers at even Sequential indices (src/utils.py:396-404)."""
+    out = []
+    for i in range(len(sizes) - 1):
+        out.append((f"{prefix}.model.{2 * i}.weight", (sizes[i + 1], sizes[i])))
+        out.append((f"{prefix}.model.{2 * i}.bias", (sizes[i + 1],)))
+    return out
+
+
+def param_shapes(d: Dims) -> Dict[str, List[Tuple[str, Tuple[int, ...]]]]:
+    """Parameter (name, shape) lists per module, in ``module.parameters()`` order."""
+    tm = [
+        ("rnn.weight_ih", (3 * d.Be, d.Be)),
+        ("rnn.weight_hh", (3 * d.Be, d.Be)),
+        ("rnn.bias_ih", (3 * d.Be,)),
+        ("rnn.bias_hh", (3 * d.Be,)),
+        ("fc_embed_state_action.0.weight", (d.Be, d.S + d.A)),
+        ("fc_embed_state_action.0.bias", (d.Be,)),
+        ("belief_prior.model.0.weight", (d.Hd, d.Be)),
+        ("belief_prior.model.0.bias", (d.Hd,)),
+        ("belief_prior.model.2.weight", (2 * d.S, d.Hd)),
+        ("belief_prior.model.2.bias", (2 * d.S,)),
+        ("belief_posterior.model.0.weight", (d.Hd, d.Be + d.E)),
+        ("belief_posterior.model.0.bias", (d.Hd,)),
+        ("belief_posterior.model.2.weight", (2 * d.S, d.Hd)),
+        ("belief_posterior.model.2.bias", (2 * d.S,)),
+    ]
+    feat = d.Be + d.S
+    hid = [d.Hd] * DENSE_LAYERS
+
+    def strip(lst):
+        return [(n.split(".", 1)[1], s) for n, s in lst]
+
+    return {
+        "transition_model": tm,
+        "observation_model": strip(_mlp_shapes("x", [feat] + hid + [d.O])),
+        "reward_model": strip(_mlp_shapes("x", [feat] + hid + [1])),
+        "encoder": strip(_mlp_shapes("x", [d.O] + hid + [d.E])),
+        "actor": strip(_mlp_shapes("x", [feat] + hid + [2 * d.A])),
+        "critic": strip(_mlp_shapes("x", [feat] + hid + [1])),
+    }
+
+
+# Order in which the reference concatenates the world-model parameters for its optimiser
+# (src/dreamer.py:160-165).
+MODEL_MODULES = ("transition_model", "observation_model", "reward_model", "encoder")
+
+
+def make_params(d: Dims, seed: int = 0) -> Dict[str, Dict[str, np.ndarray]]:
+    """PyTorch-default-like init U(-1/sqrt(fan_in), 1/sqrt(fan_in)) from a numpy stream."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out: Dict[str, Dict[str, np.ndarray]] = {}
+    for mod, lst in param_shapes(d).items():
+        sd = {}
+        fan_in = None
+        for name, shape in lst:
+            if name.startswith("rnn."):
+                bound = 1.0 / np.sqrt(d.Be)
+            elif len(shape) == 2:
+                fan_in = shape[1]
+                bound = 1.0 / np.sqrt(fan_in)
+            else:
+                bound = 1.0 / np.sqrt(fan_in)
+            sd[name] = rng.uniform(-bound, bound, size=shape).astype(np.float32)
+        out[mod] = sd
+    out["critic_target"] = {k: v.copy() for k, v in out["critic"].items()}
+    return out
+
+
+def make_replay(d: Dims, rows: int = 5000, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Synthetic replay contents: obs N(0,1), actions U(-1,1), rewards N(0,1),
+    nonterminals Bernoulli(0.999)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return {
+        "observations": rng.standard_normal((rows, d.O), dtype=np.float32),
+        "actions": rng.uniform(-1.0, 1.0, size=(rows, d.A)).astype(np.float32),
+        "rewards": rng.standard_normal((rows,), dtype=np.float32),
+        "nonterminals": (rng.random((rows, 1)) < 0.999).astype(np.float32),
+    }
+
+
+def make_batch(d: Dims, seed: int = 0, p_terminal: float = 0.02) -> Dict[str, np.ndarray]:
+    """A time-major batch as ``ExperienceReplay.sample`` returns it (src/memory.py:87-104).
+
+    Terminals are made more frequent than in the replay so that small batches exercise the
+    nonterminal mask (src/models.py:247)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 1000))
+    return {
+        "observations": rng.standard_normal((d.L, d.B, d.O), dtype=np.float32),
+        "actions": rng.uniform(-1.0, 1.0, size=(d.L, d.B, d.A)).astype(np.float32),
+        "rewards": rng.standard_normal((d.L, d.B), dtype=np.float32),
+        "nonterminals": (rng.random((d.L, d.B, 1)) >= p_terminal).astype(np.float32),
+    }
+
+
+class NoiseStream:
+    """Standard-normal draws in the reference's RNG call order (SURVEY.md section 8a, R-RNG)."""
+
+    def __init__(self, seed: int = 0):
+        self.rng = np.random.Generator(np.random.PCG64(seed + 2000))
+        self.calls: List[Tuple[int, ...]] = []
+
+    def normal(self, shape) -> np.ndarray:
+        shape = tuple(int(s) for s in shape)
+        self.calls.append(shape)
+        return self.rng.standard_normal(shape, dtype=np.float32)
+
+
+def make_noise(d: Dims, seed: int = 0) -> Dict[str, np.ndarray]:
+    """All noise of one train_step, drawn in reference order:
+    for t<T: prior (B,S) then posterior (B,S)  (src/models.py:256,267 -> :72);
+    for t<H': action (N,A), entropy (100,N,A) (src/dreamer.py:443-444), prior (N,S) (src/dreamer.py:223).
+    """
+    ns = NoiseStream(seed)
+    obs_prior = np.empty((d.T, d.B, d.S), np.float32)
+    obs_post = np.empty((d.T, d.B, d.S), np.float32)
+    for t in range(d.T):
+        obs_prior[t] = ns.normal((d.B, d.S))
+        obs_post[t] = ns.normal((d.B, d.S))
+    act = np.empty((d.Hm, d.N, d.A), np.float32)
+    ent = np.empty((d.Hm, d.n_entropy, d.N, d.A), np.float32)
+    img = np.empty((d.Hm, d.N, d.S), np.float32)
+    for t in range(d.Hm):
+        act[t] = ns.normal((d.N, d.A))
+        ent[t] = ns.normal((d.n_entropy, d.N, d.A))
+        img[t] = ns.normal((d.N, d.S))
+    return {"obs_prior": obs_prior, "obs_post": obs_post, "action": act, "entropy": ent,
+            "img_prior": img}

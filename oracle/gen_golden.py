@@ -1,0 +1,245 @@
+"""Generate golden vectors by running the *reference itself* (read-only at /root/reference) on the
+deterministic synthetic inputs of ``big_dreamer_amd.synth``.  TEST INFRASTRUCTURE.
+
+Runs only in the build container (the reference does not exist on the GPU box).  Output:
+``tests/golden/<config>.npz`` -- data only (inputs are re-derivable from seeds, outputs are stored).
+
+The reference imports need four inert stubs for packages that are absent here and do no arithmetic
+(SURVEY.md section 8c): torchtyping, typeguard (decorators), cv2, gym.
+
+Noise is *injected* rather than captured: ``torch.randn_like`` and
+``torch.distributions.normal._standard_normal`` are replaced by draws from ``synth.NoiseStream`` so the
+reference consumes exactly the arrays ``synth.make_noise`` reproduces later.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from big_dreamer_amd import synth  # noqa: E402
+
+REF = "/root/reference/src"
+
+
+def _import_reference():
+    tt = types.ModuleType("torchtyping")
+
+    class _TT:
+        def __class_getitem__(cls, item):
+            return torch.Tensor
+
+    tt.TensorType = _TT
+    tt.patch_typeguard = lambda: None
+    tg = types.ModuleType("typeguard")
+    tg.typechecked = lambda f: f
+    sys.modules.update({"torchtyping": tt, "typeguard": tg, "cv2": types.ModuleType("cv2"),
+                        "gym": types.ModuleType("gym")})
+    sys.path.insert(0, REF)
+    import utils
+    utils.init_gpu(use_gpu=False)          # must precede dreamer/planet imports (they bind `device` by value)
+    import dreamer
+    import memory
+    return dreamer, memory
+
+
+class FakeEnv:
+    def __init__(self, d):
+        self.action_size = d.A
+        self.observation_size = d.O
+
+
+def ref_params(d: synth.Dims, **over):
+    with open(os.path.join(REF, "conf", "config.yaml")) as f:
+        p = yaml.safe_load(f)
+
+    def coerce(x):   # PyYAML (YAML 1.1) reads "2e-4" as str; OmegaConf/hydra read it as float
+        if isinstance(x, dict):
+            return {k: coerce(v) for k, v in x.items()}
+        if isinstance(x, str):
+            try:
+                return float(x)
+            except ValueError:
+                return x
+        return x
+
+    p = coerce(p)
+    p.update(dict(disable_cuda=True, pixel_observation=False, belief_size=d.Be, state_size=d.S,
+                  hidden_size=d.Hd, embedding_size=d.E, batch_size=d.B, seq_len=d.L,
+                  planning_horizon=d.H, experience_size=6000))
+    p.update(over)
+    return p
+
+
+class Inject:
+    """Context manager replacing the reference's normal draws by a NoiseStream."""
+
+    def __init__(self, stream: synth.NoiseStream):
+        self.s = stream
+
+    def __enter__(self):
+        import torch.distributions.normal as tdn
+        self._rl, self._sn = torch.randn_like, tdn._standard_normal
+        torch.randn_like = lambda x, **kw: torch.from_numpy(self.s.normal(x.shape))
+        tdn._standard_normal = lambda shape, dtype, device: torch.from_numpy(self.s.normal(tuple(shape)))
+        return self
+
+    def __exit__(self, *a):
+        import torch.distributions.normal as tdn
+        torch.randn_like, tdn._standard_normal = self._rl, self._sn
+
+
+def build_agent(dreamer_mod, d, P, **over):
+    agent = dreamer_mod.Dreamer(ref_params(d, **over), FakeEnv(d))
+    for mod in ("transition_model", "observation_model", "reward_model", "encoder", "actor", "critic",
+                "critic_target"):
+        getattr(agent, mod).load_state_dict({k: torch.from_numpy(v.copy()) for k, v in P[mod].items()})
+    return agent
+
+
+def t2n(x):
+    return x.detach().numpy().copy()
+
+
+def store(out, key, a, full):
+    """Full tensor for the small cases; (sum, abssum, strided 257-sample) for the full-size configs."""
+    if full or a.size <= 64:
+        out[key] = a
+    else:
+        out[key + ".sum"] = np.array(a.astype(np.float64).sum())
+        out[key + ".abssum"] = np.array(np.abs(a.astype(np.float64)).sum())
+        out[key + ".sample"] = a.reshape(-1)[:: max(1, a.size // 257)][:257].copy()
+
+
+def run_config(dreamer_mod, name: str, d: synth.Dims, full: bool, seed: int = 0, **over):
+    out = {}
+    P = synth.make_params(d, seed)
+    batch = synth.make_batch(d, seed)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+
+    # ---- piecewise: R-enc, R1, R3 on the initial weights ------------------------------------
+    agent = build_agent(dreamer_mod, d, P, **over)
+    ns = synth.NoiseStream(seed)
+    with Inject(ns):
+        emb = agent.encoder(tb["observations"][1:])
+        beliefs, prior_states, prior_params, post_states, post_params = agent.transition_model(
+            torch.zeros(d.B, d.S), tb["actions"][:-1], torch.zeros(d.B, d.Be), emb, tb["nonterminals"][:-1])
+        obs_loss = agent._observation_loss(beliefs, post_states, tb["observations"][1:])
+        rew_loss = agent._reward_loss(beliefs, post_states, tb["rewards"][:-1])
+        kl = agent._kl_loss(post_params, prior_params)
+        # R4-R6 on the same weights (imagination from detached posteriors)
+        img_b, img_s, img_params, ent = agent.imagine_ahead(post_states.detach(), beliefs.detach())
+        img_r = agent.reward_model(img_b, img_s)
+        img_v = agent.critic_target(img_b, img_s)
+        ret = dreamer_mod.lambda_return(img_r, img_v, bootstrap=img_v[-1], discount=agent.discount,
+                                        lambda_=agent.disclam)
+    # the stream must have been consumed in exactly make_noise order
+    ref_calls = list(ns.calls)
+    ns3 = synth.NoiseStream(seed)
+    for t in range(d.T):
+        ns3.normal((d.B, d.S)); ns3.normal((d.B, d.S))
+    for t in range(d.Hm):
+        ns3.normal((d.N, d.A)); ns3.normal((d.n_entropy, d.N, d.A)); ns3.normal((d.N, d.S))
+    assert ref_calls == ns3.calls, "reference RNG call order differs from synth.make_noise"
+
+    piece = dict(embeddings=emb, beliefs=beliefs, prior_states=prior_states, prior_means=prior_params[0],
+                 prior_stds=prior_params[1], posterior_states=post_states, posterior_means=post_params[0],
+                 posterior_stds=post_params[1], observation_loss=obs_loss, reward_loss=rew_loss, kl_loss=kl,
+                 imged_beliefs=img_b, imged_states=img_s, imged_prior_means=img_params[0],
+                 imged_prior_stds=img_params[1], action_entropy=ent, imged_reward=img_r, value_pred=img_v,
+                 returns=ret)
+    for k, v in piece.items():
+        store(out, f"piece.{k}", t2n(v), full)
+
+    # ---- kl_balance == -1 branch (dreamer.py:122-128) ---------------------------------------
+    agent.kl_balance = -1
+    out["piece.kl_loss_sum_branch"] = t2n(agent._kl_loss(post_params, prior_params))
+    agent.kl_balance = ref_params(d, **over)["kl_balance"]
+
+    # ---- whole train_step x2, fresh agent ----------------------------------------------------
+    agent = build_agent(dreamer_mod, d, P, **over)
+    agent.buffer.sample = lambda n, L: [tb["observations"], tb["actions"], tb["rewards"], tb["nonterminals"]]
+    norms = []
+    orig_clip = torch.nn.utils.clip_grad_norm_
+
+    def rec_clip(params, max_norm, norm_type=2):
+        r = orig_clip(params, max_norm, norm_type=norm_type)
+        norms.append(float(r))
+        return r
+
+    torch.nn.utils.clip_grad_norm_ = rec_clip
+    try:
+        for step in range(2):
+            with Inject(synth.NoiseStream(seed + step)):
+                logs = agent.train_step()
+            if step == 0:
+                agent.update_critic()      # exercised between steps (main.py:110-112)
+            for k, v in logs.items():
+                out[f"step{step}.log.{k}"] = np.array(v, dtype=np.float64)
+            out[f"step{step}.grad_norms"] = np.array(norms[-3:], dtype=np.float64)
+            for mod in ("transition_model", "observation_model", "reward_model", "encoder", "actor", "critic",
+                        "critic_target"):
+                for k, p in getattr(agent, mod).state_dict().items():
+                    a = t2n(p)
+                    store(out, f"step{step}.param.{mod}.{k}", a, full)
+                if mod == "critic_target":
+                    continue
+                for k, p in getattr(agent, mod).named_parameters():
+                    g = t2n(p.grad)           # gradients after clipping (dreamer.py:301,364,388)
+                    store(out, f"step{step}.grad.{mod}.{k}", g, full)
+    finally:
+        torch.nn.utils.clip_grad_norm_ = orig_clip
+
+    # fingerprints of the synthetic inputs, so a drifted numpy stream is detected, not mis-compared
+    out["fingerprint.params"] = np.array(sum(float(np.abs(v.astype(np.float64)).sum()) for sd in P.values()
+                                             for v in sd.values()))
+    out["fingerprint.batch"] = np.array(sum(float(np.abs(v.astype(np.float64)).sum()) for v in batch.values()))
+    nz = synth.make_noise(d, seed)
+    out["fingerprint.noise"] = np.array(sum(float(np.abs(v.astype(np.float64)).sum()) for v in nz.values()))
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def run_replay(memory_mod):
+    """R0: ExperienceReplay.sample index/gather semantics (src/memory.py:51-104)."""
+    d = synth.TINY
+    rows = 64
+    rep = synth.make_replay(d, rows=rows, seed=3)
+    out = {}
+    for case, (idx, full) in {"partial": (40, False), "wrapped": (17, True)}.items():
+        buf = memory_mod.ExperienceReplay(rows, d.A, 5, False, d.O, torch.device("cpu"))
+        buf.observations[:] = rep["observations"]; buf.actions[:] = rep["actions"]
+        buf.rewards[:] = rep["rewards"]; buf.nonterminals[:] = rep["nonterminals"]
+        buf.idx, buf.full = idx, full
+        np.random.seed(11)
+        o, a, r, n = buf.sample(6, 7)
+        out[f"{case}.observations"] = t2n(o); out[f"{case}.actions"] = t2n(a)
+        out[f"{case}.rewards"] = t2n(r); out[f"{case}.nonterminals"] = t2n(n)
+    path = os.path.join(ROOT, "tests", "golden", "replay.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    dreamer_mod, memory_mod = _import_reference()
+    run_replay(memory_mod)
+    run_config(dreamer_mod, "tiny", synth.TINY, full=True)
+    run_config(dreamer_mod, "small", synth.SMALL, full=True, seed=1)
+    # the sum-KL branch end to end (kl_balance = -1) and an unsaturated free-nats setting
+    run_config(dreamer_mod, "tiny_klsum", synth.TINY, full=True, seed=2, kl_balance=-1, free_nats=0.05)
+    run_config(dreamer_mod, "tiny_freenats0", synth.TINY, full=True, seed=3, free_nats=0.0)
+    run_config(dreamer_mod, "config1", synth.CONFIG1, full=False)
+    run_config(dreamer_mod, "config2", synth.CONFIG2, full=False)
+
+
+if __name__ == "__main__":
+    main()
