@@ -1,0 +1,71 @@
+// cabi.hip -- error reporting, version, weight packing, replay gather.
+#include "bd_device.h"
+#include "bd_host.h"
+
+namespace bd {
+char* err_buf() {
+    static thread_local char buf[512] = "";
+    return buf;
+}
+
+// One block column per descriptor (blockIdx.y); blockIdx.x strides over its 16x16 blocks; each thread
+// writes one packed float4: dst[(nb*Kb + kb)*64 + lane] = {W[n][k0..k0+3]}, n = nb*16 + (lane&15),
+// k0 = kb*16 + 4*(lane>>4); transposed descriptors read W[k][n] instead.
+__global__ __launch_bounds__(256) void pack_kernel(const bd_pack_desc* __restrict__ descs) {
+    const bd_pack_desc d = descs[blockIdx.y];
+    const int No = d.transpose ? d.K : d.N;   // packed "out" dim
+    const int Ki = d.transpose ? d.N : d.K;   // packed "in" dim
+    const int Nb = (No + 15) >> 4, Kb = (Ki + 15) >> 4;
+    const int total = Nb * Kb * 64;
+    floatx4* __restrict__ dst = reinterpret_cast<floatx4*>(d.dst);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int lane = e & 63, blk = e >> 6;
+        const int nb = blk / Kb, kb = blk - nb * Kb;
+        const int n = nb * 16 + (lane & 15);
+        const int k0 = kb * 16 + 4 * (lane >> 4);
+        floatx4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + i;
+            float x = 0.f;
+            if (n < No && k < Ki) x = d.transpose ? d.src[(size_t)k * d.ld + n] : d.src[(size_t)n * d.ld + k];
+            v[i] = x;
+        }
+        dst[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                          int n_idx, int width, float* __restrict__ dst) {
+    const size_t total = (size_t)n_idx * width;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / width, c = e - r * width;
+        dst[e] = src[(size_t)idx[r] * width + c];
+    }
+}
+}  // namespace bd
+
+extern "C" {
+
+const char* bd_last_error(void) { return bd::err_buf(); }
+int bd_version(void) { return 1; }
+
+size_t bd_packed_floats(int N, int K) { return (size_t)bd::cdiv(N, 16) * bd::cdiv(K, 16) * 256; }
+
+int bd_pack_weights(const bd_pack_desc* descs, int n, void* stream) {
+    BD_REQUIRE(descs != nullptr && n > 0, "bd_pack_weights: no descriptors");
+    hipLaunchKernelGGL(bd::pack_kernel, dim3(16, n), dim3(256), 0, (hipStream_t)stream, descs);
+    BD_CHECK_LAUNCH("bd_pack_weights");
+    return 0;
+}
+
+int bd_replay_gather(const float* src, const int64_t* idx, int n_idx, int width, float* dst, void* stream) {
+    BD_REQUIRE(src && idx && dst && n_idx > 0 && width > 0, "bd_replay_gather: bad arguments");
+    const size_t total = (size_t)n_idx * width;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(bd::gather_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, idx, n_idx, width, dst);
+    BD_CHECK_LAUNCH("bd_replay_gather");
+    return 0;
+}
+
+}  // extern "C"

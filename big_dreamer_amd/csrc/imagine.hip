@@ -1,0 +1,476 @@
+// imagine.hip -- imagination rollout (Dreamer.imagine_ahead, src/dreamer.py:179-237) with the actor
+// (ActorModel, src/models.py:506-517), the tanh-Normal action sample and its 100-sample entropy estimate
+// (Dreamer.get_action src/dreamer.py:429-444; SampleDist.entropy / TanhBijector src/models.py:630-733), and
+// the backward pass through the whole rollout.  One persistent launch per direction; a workgroup owns 16
+// trajectories for all Hm steps (trajectories are independent: no inter-workgroup synchronisation), all
+// per-step vectors stay in LDS in MFMA fragment order, weights stream from L2.
+//
+// Per step t (src/dreamer.py:213-227), from (h, s):
+//   actor: 4 x (Linear+ELU) on [h; s] (detached), out -> mean = 5 tanh(m/5), std = softplus(r + c0) + 1e-4
+//   a = tanh(mean + std*eps_a);   entropy = -mean_k log p(tanh(mean + std*eps_k))
+//   x = ELU(W_e [s; a] + b_e);  h' = GRUCell(x, h);  p = ELU(W_p1 h' + b);  s' = mean_p + std_p * eps_p
+#include "bd_device.h"
+#include "bd_host.h"
+
+namespace bd {
+
+constexpr int kMaxA = 64;
+
+struct ImgDims {
+    int Kb_h, Kb_s, Kb_a, Kb_hd;
+    __host__ __device__ ImgDims(int Be, int S, int A, int Hd)
+        : Kb_h(cdiv(Be, 16)), Kb_s(cdiv(S, 16)), Kb_a(cdiv(A, 16)), Kb_hd(cdiv(Hd, 16)) {}
+};
+
+// One sample of the entropy estimate: log-density of y = tanh(mean + std*e) under the tanh-Normal, and its
+// derivatives w.r.t. mean and std following the reference's autograd graph (rsample -> tanh -> clamp ->
+// atanh -> Normal.log_prob - log|det J|).
+__device__ __forceinline__ void entropy_sample(float mean, float sd, float e, float& lp, float& dm, float& ds) {
+    constexpr float kClamp = 0.99999994f;                // float32(0.99999997), src/models.py:663
+    constexpr float kLogSqrt2Pi = 0.91893853320467274f;
+    constexpr float kLn2 = 0.69314718055994531f;
+    const float u = mean + sd * e;
+    const float y = tanhf(u);
+    const float yc = fminf(fmaxf(y, -kClamp), kClamp);
+    const float a = 1.f + yc, b = 1.f - yc;
+    const float w = a / b;
+    const float xh = 0.5f * logf(w);                     // atanh (src/models.py:627)
+    const float diff = xh - mean;
+    const float inv_var = 1.f / (sd * sd);
+    const float base = -(diff * diff) * 0.5f * inv_var - logf(sd) - kLogSqrt2Pi;
+    const float ladj = 2.f * (kLn2 - xh - softplusf(-2.f * xh));   // src/models.py:673
+    lp = base - ladj;
+    const float gx = -diff * inv_var + 2.f - 4.f * sigmoidf(-2.f * xh);     // d lp / d xh
+    const bool pass = (y >= -kClamp) && (y <= kClamp);                      // clamp backward mask
+    const float J = pass ? (1.f - y * y) * (0.5f / w) * (1.f / b + a / (b * b)) : 0.f;   // d xh / d u
+    dm = diff * inv_var + gx * J;
+    ds = diff * diff * inv_var / sd - 1.f / sd + gx * J * e;
+}
+
+// hidden layer epilogue: ELU -> LDS fragment (+ optional save for the backward)
+struct HiddenEpi {
+    float* dst;
+    float* save;
+    size_t tn;
+    int width, rows, row0, lane;
+    __device__ __forceinline__ void operator()(int nb, floatx4 acc) const {
+        const int col = nb * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int grow = row0 + 4 * (lane >> 4) + r;
+            const bool ok = grow < rows && col < width;
+            const float v = ok ? elu(acc[r]) : 0.f;
+            dst[acc_frag_off(nb, lane, r)] = v;
+            if (ok && save) save[(tn + grow) * width + col] = v;
+        }
+    }
+};
+
+// "gradient w.r.t. a hidden ELU output" epilogue: multiply by ELU' (from the saved output), keep in LDS for the
+// next contraction (dst may be null) and store for bd_wgrad (out may be null).
+struct DpreEpi {
+    float* dst;
+    const float* saved;
+    float* out;
+    size_t tn;
+    int width, rows, row0, lane;
+    __device__ __forceinline__ void operator()(int nb, floatx4 acc) const {
+        const int col = nb * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int grow = row0 + 4 * (lane >> 4) + r;
+            float v = 0.f;
+            if (grow < rows && col < width) {
+                v = acc[r] * elu_grad_from_out(saved[(tn + grow) * width + col]);
+                if (out) out[(tn + grow) * width + col] = v;
+            }
+            if (dst) dst[acc_frag_off(nb, lane, r)] = v;
+        }
+    }
+};
+
+__global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const ImgDims d(a.Be, a.S, a.A, a.Hd);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * 16;
+    const int F = a.Be + a.S, A = a.A;
+    const int nh = d.Kb_h * kFragFloats, nhd = d.Kb_hd * kFragFloats;
+    float* h_cur = smem;
+    float* h_nxt = h_cur + nh;
+    float* xf = h_nxt + nh;
+    float* bufA = xf + nh;
+    float* bufB = bufA + nhd;
+    float* sf = bufB + nhd;
+    float* af = sf + d.Kb_s * kFragFloats;
+    float* mean_s = af + d.Kb_a * kFragFloats;    // [16][A]
+    float* std_s = mean_s + 16 * A;               // [16][A]
+    float* lp_rj = std_s + 16 * A;                // [16][A]
+    float* part = lp_rj + 16 * A;                 // [4][16][A][3]
+
+    load_tile_concat<1>(h_cur, d.Kb_h, row0, a.N, a.start_feat, F, a.Be, nullptr, 0, 0);
+    load_tile_concat<1>(sf, d.Kb_s, row0, a.N, a.start_feat + a.Be, F, a.S, nullptr, 0, 0);
+    __syncthreads();
+
+    const GruW gw{a.w_ir, a.w_iz, a.w_in, a.w_hr, a.w_hz, a.w_hn, a.b_ih, a.b_hh};
+    const size_t act_stride = (size_t)a.Hm * a.N * a.Hd;
+    const float inv_ns = 1.f / (float)a.n_samples;
+
+    // hidden layer epilogue: ELU -> LDS fragment (+ optional save)
+    auto hidden_epi = [&](float* dst, float* save, size_t tn, int width) {
+        return HiddenEpi{dst, save, tn, width, a.N, row0, lane};
+    };
+
+    for (int t = 0; t < a.Hm; ++t) {
+        const size_t tn = (size_t)t * a.N;
+        // ---- actor hidden layers ----
+        {
+            const Seg segs[2] = {{h_cur, a.w_a0h, d.Kb_h}, {sf, a.w_a0s, d.Kb_s}};
+            tile_linear_seg<4, 2>(segs, a.b_a[0], a.Hd, hidden_epi(bufA, a.sv_actor, tn, a.Hd));
+        }
+        __syncthreads();
+        {
+            float* src = bufA;
+            float* dst = bufB;
+            for (int l = 1; l < 4; ++l) {
+                const Seg segs[1] = {{src, a.w_a[l - 1], d.Kb_hd}};
+                tile_linear_seg<4, 1>(segs, a.b_a[l], a.Hd,
+                                      hidden_epi(dst, a.sv_actor ? a.sv_actor + l * act_stride : nullptr, tn, a.Hd));
+                __syncthreads();
+                float* tmp = src; src = dst; dst = tmp;
+            }
+            // after 3 layers the activations of layer 3 are in bufB (A->B, B->A, A->B)
+        }
+        // ---- actor output, action sample ----
+        {
+            const Seg2 segs[1] = {{bufB, a.w_a4m, a.w_a4s, d.Kb_hd}};
+            tile_linear_dual<1>(segs, a.b_a4, a.b_a4 + A, A, [&](int nb, floatx4 Mn, floatx4 Rw) {
+                const int col = nb * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * (lane >> 4) + r, grow = row0 + row;
+                    float act = 0.f;
+                    if (grow < a.N && col < A) {
+                        const float th = tanhf(Mn[r] / a.act_mean_scale);
+                        const float mean = a.act_mean_scale * th;
+                        const float pre = Rw[r] + a.act_raw_init_std;
+                        const float sd = softplusf(pre) + a.act_min_std;
+                        act = tanhf(mean + sd * a.eps_action[(tn + grow) * A + col]);
+                        a.action[(tn + grow) * A + col] = act;
+                        mean_s[row * A + col] = mean;
+                        std_s[row * A + col] = sd;
+                        if (a.sv_act_stats) {
+                            float* st = a.sv_act_stats + (tn + grow) * 4 * A + col;
+                            st[0] = th;
+                            st[A] = sigmoidf(pre);
+                        }
+                    }
+                    af[acc_frag_off(nb, lane, r)] = act;
+                }
+            });
+        }
+        __syncthreads();
+        // ---- entropy: n_samples draws per (row, action dim); thread = (row, sample lane) ----
+        {
+            const int row = threadIdx.x & 15, sl = threadIdx.x >> 4;   // 16 sample lanes
+            const int grow = row0 + row;
+            for (int j = 0; j < A; ++j) {
+                float lp = 0.f, dm = 0.f, ds = 0.f;
+                if (grow < a.N) {
+                    const float mean = mean_s[row * A + j], sd = std_s[row * A + j];
+                    for (int k = sl; k < a.n_samples; k += 16) {
+                        const float e = a.eps_entropy[(((size_t)t * a.n_samples + k) * a.N + grow) * A + j];
+                        float l1, d1, d2;
+                        entropy_sample(mean, sd, e, l1, d1, d2);
+                        lp += l1; dm += d1; ds += d2;
+                    }
+                }
+                // the 4 sample lanes of this wave that share `row` sit 16 lanes apart
+                lp += __shfl_xor(lp, 16, 64); lp += __shfl_xor(lp, 32, 64);
+                dm += __shfl_xor(dm, 16, 64); dm += __shfl_xor(dm, 32, 64);
+                ds += __shfl_xor(ds, 16, 64); ds += __shfl_xor(ds, 32, 64);
+                if (lane < 16) {
+                    float* p = part + ((wave * 16 + row) * A + j) * 3;
+                    p[0] = lp; p[1] = dm; p[2] = ds;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 16 * A; i += blockDim.x) {
+            const int row = i / A, j = i - row * A, grow = row0 + row;
+            float lp = 0.f, dm = 0.f, ds = 0.f;
+            for (int w = 0; w < kWaves; ++w) {
+                const float* p = part + ((w * 16 + row) * A + j) * 3;
+                lp += p[0]; dm += p[1]; ds += p[2];
+            }
+            lp_rj[i] = lp;
+            if (grow < a.N && a.sv_act_stats) {
+                float* st = a.sv_act_stats + (tn + grow) * 4 * A + j;
+                st[2 * A] = -dm * inv_ns;     // d entropy / d mean
+                st[3 * A] = -ds * inv_ns;     // d entropy / d std
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 16 && row0 + threadIdx.x < a.N) {
+            float s = 0.f;
+            for (int j = 0; j < A; ++j) s += lp_rj[threadIdx.x * A + j];
+            a.entropy[tn + row0 + threadIdx.x] = -s * inv_ns;
+        }
+        // ---- embed ----
+        {
+            const Seg segs[2] = {{sf, a.w_embed_s, d.Kb_s}, {af, a.w_embed_a, d.Kb_a}};
+            tile_linear_seg<4, 2>(segs, a.b_embed, a.Be, hidden_epi(xf, a.sv_x, tn, a.Be));
+        }
+        __syncthreads();
+        // ---- GRU ----
+        gru_tile(xf, h_cur, d.Kb_h, a.Be, gw, [&](int nb, floatx4 R, floatx4 Z, floatx4 NI, floatx4 NH) {
+            const int col = nb * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int grow = row0 + 4 * (lane >> 4) + r;
+                const int off = acc_frag_off(nb, lane, r);
+                const float rr = sigmoidf(R[r]), zz = sigmoidf(Z[r]);
+                const float nn = tanhf(NI[r] + rr * NH[r]);
+                const float hn = (1.f - zz) * nn + zz * h_cur[off];
+                const bool ok = grow < a.N && col < a.Be;
+                h_nxt[off] = ok ? hn : 0.f;
+                if (ok) {
+                    a.feat[(tn + grow) * F + col] = hn;
+                    if (a.sv_gates) {
+                        float* g = a.sv_gates + (tn + grow) * 4 * a.Be + col;
+                        g[0] = rr; g[a.Be] = zz; g[2 * a.Be] = nn; g[3 * a.Be] = NH[r];
+                    }
+                }
+            }
+        });
+        __syncthreads();
+        // ---- prior ----
+        {
+            const Seg segs[1] = {{h_nxt, a.w_p1, d.Kb_h}};
+            tile_linear_seg<4, 1>(segs, a.b_p1, a.Hd, hidden_epi(bufA, a.sv_p, tn, a.Hd));
+        }
+        __syncthreads();
+        {
+            const Seg2 segs[1] = {{bufA, a.w_p2m, a.w_p2s, d.Kb_hd}};
+            tile_linear_dual<1>(segs, a.b_p2, a.b_p2 + a.S, a.S, [&](int nb, floatx4 Mn, floatx4 Rw) {
+                const int col = nb * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int grow = row0 + 4 * (lane >> 4) + r;
+                    float st = 0.f;
+                    if (grow < a.N && col < a.S) {
+                        const size_t i = (tn + grow) * a.S + col;
+                        const float sd = softplusf(Rw[r]) + a.min_std;
+                        st = Mn[r] + sd * a.eps_prior[i];
+                        if (a.prior_mean) a.prior_mean[i] = Mn[r];
+                        a.prior_std[i] = sd;
+                        a.feat[(tn + grow) * F + a.Be + col] = st;
+                    }
+                    sf[acc_frag_off(nb, lane, r)] = st;
+                }
+            });
+        }
+        __syncthreads();
+        float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
+    }
+}
+
+// ---- backward --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const ImgDims d(a.Be, a.S, a.A, a.Hd);
+    const int lane = threadIdx.x & 63;
+    const int row0 = blockIdx.x * 16;
+    const int F = a.Be + a.S, A = a.A;
+    const int nh = d.Kb_h * kFragFloats, nhd = d.Kb_hd * kFragFloats, ns = d.Kb_s * kFragFloats,
+              na = d.Kb_a * kFragFloats;
+    float* dhc = smem;
+    float* dR = dhc + nh;
+    float* dZ = dR + nh;
+    float* dNI = dZ + nh;
+    float* dNH = dNI + nh;
+    float* dE = dNH + nh;
+    float* dP = dE + nh;          // Kb_hd
+    float* bufA = dP + nhd;
+    float* bufB = bufA + nhd;
+    float* dM = bufB + nhd;       // Kb_s
+    float* dRaw = dM + ns;
+    float* dAm = dRaw + ns;       // Kb_a
+    float* dAr = dAm + na;
+    float* ds_plain = dAr + na;   // [16][S]
+
+    for (int i = threadIdx.x; i < nh; i += blockDim.x) dhc[i] = 0.f;
+    for (int i = threadIdx.x; i < 16 * a.S; i += blockDim.x) ds_plain[i] = 0.f;
+    __syncthreads();
+
+    const GruWT gw{a.wt_ir, a.wt_iz, a.wt_in, a.wt_hr, a.wt_hz, a.wt_hn};
+    const size_t act_stride = (size_t)a.Hm * a.N * a.Hd;
+
+    auto dpre_epi = [&](float* dst, const float* saved, float* out, size_t tn, int width) {
+        return DpreEpi{dst, saved, out, tn, width, a.N, row0, lane};
+    };
+
+    for (int t = a.Hm - 1; t >= 0; --t) {
+        const size_t tn = (size_t)t * a.N;
+        // ---- 1: prior sample -> (mean, raw) ----
+        for (int i = threadIdx.x; i < 16 * d.Kb_s * 16; i += blockDim.x) {
+            const int r = i / (d.Kb_s * 16), k = i - r * (d.Kb_s * 16);
+            const int grow = row0 + r;
+            float dm = 0.f, dr = 0.f;
+            if (grow < a.N && k < a.S) {
+                const size_t idx = (tn + grow) * a.S + k;
+                dm = ds_plain[r * a.S + k] + a.dfeat[(tn + grow) * F + a.Be + k];
+                dr = dm * a.eps_prior[idx] * (-expm1f(-(a.prior_std[idx] - a.min_std)));
+            }
+            dM[frag_idx(r, k)] = dm;
+            dRaw[frag_idx(r, k)] = dr;
+        }
+        __syncthreads();
+        // ---- 2: prior hidden ----
+        {
+            const Seg segs[2] = {{dM, a.wt_p2m, d.Kb_s}, {dRaw, a.wt_p2s, d.Kb_s}};
+            tile_linear_seg<4, 2>(segs, nullptr, a.Hd, dpre_epi(dP, a.sv_p, nullptr, tn, a.Hd));
+        }
+        __syncthreads();
+        // ---- 3: total d belief_{t+1}; GRU gates ----
+        tile_linear<1, 4>(dP, d.Kb_hd, a.wt_p1, nullptr, a.Be, [&](int, int nb, floatx4 acc) {
+            const int col = nb * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int grow = row0 + 4 * (lane >> 4) + r;
+                const int off = acc_frag_off(nb, lane, r);
+                float vr = 0.f, vz = 0.f, vni = 0.f, vnh = 0.f, carry = 0.f;
+                if (grow < a.N && col < a.Be) {
+                    const float dh = acc[r] + dhc[off] + a.dfeat[(tn + grow) * F + col];
+                    const float* g = a.sv_gates + (tn + grow) * 4 * a.Be + col;
+                    const float rr = g[0], zz = g[a.Be], nn = g[2 * a.Be], hn = g[3 * a.Be];
+                    const float hprev = t > 0 ? a.feat[(tn - a.N + grow) * F + col] : a.start_feat[(size_t)grow * F + col];
+                    const float dn = dh * (1.f - zz);
+                    const float dz = dh * (hprev - nn);
+                    vni = dn * (1.f - nn * nn);
+                    vnh = vni * rr;
+                    vr = vni * hn * rr * (1.f - rr);
+                    vz = dz * zz * (1.f - zz);
+                    carry = dh * zz;
+                }
+                dR[off] = vr; dZ[off] = vz; dNI[off] = vni; dNH[off] = vnh;
+                dhc[off] = carry;
+            }
+        });
+        __syncthreads();
+        // ---- 4: through W_ih / W_hh ----
+        gru_tile_bwd(dR, dZ, dNI, dNH, d.Kb_h, a.Be, gw, [&](int nb, floatx4 DX, floatx4 DH) {
+            const int col = nb * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int grow = row0 + 4 * (lane >> 4) + r;
+                const int off = acc_frag_off(nb, lane, r);
+                float de = 0.f;
+                if (grow < a.N && col < a.Be) {
+                    de = DX[r] * elu_grad_from_out(a.sv_x[(tn + grow) * a.Be + col]);
+                    dhc[off] += DH[r];
+                }
+                dE[off] = de;
+            }
+        });
+        __syncthreads();
+        // ---- 5: embed layer -> d state_t (carry) and d action_t -> actor output gradients ----
+        tile_linear<1, 4>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
+            const int col = nb * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * (lane >> 4) + r;
+                if (col < a.S) ds_plain[row * a.S + col] = (row0 + row < a.N) ? acc[r] : 0.f;
+            }
+        });
+        tile_linear<1, 4>(dE, d.Kb_h, a.wt_embed_a, nullptr, A, [&](int, int nb, floatx4 acc) {
+            const int col = nb * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int grow = row0 + 4 * (lane >> 4) + r;
+                float gm = 0.f, gr = 0.f;
+                if (grow < a.N && col < A) {
+                    const size_t i = (tn + grow) * A + col;
+                    const float act = a.action[i];
+                    const float* st = a.sv_act_stats + (tn + grow) * 4 * A + col;
+                    const float th = st[0], sg = st[A], dent_dmean = st[2 * A], dent_dstd = st[3 * A];
+                    const float dxa = acc[r] * (1.f - act * act);                  // through a = tanh(x)
+                    const float dmean = dxa + a.dentropy * dent_dmean;
+                    const float dstd = dxa * a.eps_action[i] + a.dentropy * dent_dstd;
+                    gm = dmean * (1.f - th * th);      // mean = scale * tanh(m / scale)
+                    gr = dstd * sg;                    // std = softplus(r + c0) + min
+                    a.d_actor_out[(tn + grow) * 2 * A + col] = gm;
+                    a.d_actor_out[(tn + grow) * 2 * A + A + col] = gr;
+                }
+                dAm[acc_frag_off(nb, lane, r)] = gm;
+                dAr[acc_frag_off(nb, lane, r)] = gr;
+            }
+        });
+        __syncthreads();
+        // ---- 6: actor MLP backward (input detached: no gradient below layer 0) ----
+        {
+            const Seg segs[2] = {{dAm, a.wt_a4m, d.Kb_a}, {dAr, a.wt_a4s, d.Kb_a}};
+            tile_linear_seg<4, 2>(segs, nullptr, a.Hd,
+                                  dpre_epi(bufA, a.sv_actor + 3 * act_stride, a.d_actor_pre + 3 * act_stride, tn, a.Hd));
+        }
+        __syncthreads();
+        {
+            float* src = bufA;
+            float* dst = bufB;
+            for (int l = 2; l >= 0; --l) {
+                const Seg segs[1] = {{src, a.wt_a[l], d.Kb_hd}};
+                tile_linear_seg<4, 1>(segs, nullptr, a.Hd,
+                                      dpre_epi(l > 0 ? dst : nullptr, a.sv_actor + l * act_stride,
+                                               a.d_actor_pre + l * act_stride, tn, a.Hd));
+                __syncthreads();
+                float* tmp = src; src = dst; dst = tmp;
+            }
+        }
+    }
+}
+
+}  // namespace bd
+
+extern "C" {
+using namespace bd;
+
+int bd_imagine_forward(const bd_imagine_fwd_args* a, void* stream) {
+    BD_REQUIRE(a && a->N > 0 && a->Hm > 0 && a->Be > 0 && a->S > 0 && a->A > 0 && a->A <= kMaxA && a->Hd > 0 &&
+                   a->n_samples > 0, "bd_imagine_forward: bad dims");
+    BD_REQUIRE(a->w_embed_s && a->w_embed_a && a->b_embed && a->w_ir && a->w_iz && a->w_in && a->w_hr && a->w_hz &&
+                   a->w_hn && a->b_ih && a->b_hh && a->w_p1 && a->b_p1 && a->w_p2m && a->w_p2s && a->b_p2,
+               "bd_imagine_forward: missing world-model weights");
+    BD_REQUIRE(a->w_a0h && a->w_a0s && a->w_a[0] && a->w_a[1] && a->w_a[2] && a->b_a[0] && a->b_a[1] && a->b_a[2] &&
+                   a->b_a[3] && a->w_a4m && a->w_a4s && a->b_a4, "bd_imagine_forward: missing actor weights");
+    BD_REQUIRE(a->start_feat && a->eps_action && a->eps_entropy && a->eps_prior, "bd_imagine_forward: missing inputs");
+    BD_REQUIRE(a->feat && a->prior_std && a->entropy && a->action, "bd_imagine_forward: missing outputs");
+    const ImgDims d(a->Be, a->S, a->A, a->Hd);
+    const size_t lds = ((size_t)(3 * d.Kb_h + 2 * d.Kb_hd + d.Kb_s + d.Kb_a) * kFragFloats + (size_t)(3 * 16 + 4 * 16 * 3) * a->A) *
+                       sizeof(float);
+    BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_imagine_forward: needs %zu B of LDS", lds);
+    if (lds > 64 * 1024 && allow_big_lds(imagine_fwd_kernel)) return -1;
+    hipLaunchKernelGGL(imagine_fwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);
+    BD_CHECK_LAUNCH("bd_imagine_forward");
+    return 0;
+}
+
+int bd_imagine_backward(const bd_imagine_bwd_args* a, void* stream) {
+    BD_REQUIRE(a && a->N > 0 && a->Hm > 0 && a->Be > 0 && a->S > 0 && a->A > 0 && a->A <= kMaxA && a->Hd > 0,
+               "bd_imagine_backward: bad dims");
+    BD_REQUIRE(a->wt_embed_s && a->wt_embed_a && a->wt_ir && a->wt_iz && a->wt_in && a->wt_hr && a->wt_hz && a->wt_hn &&
+                   a->wt_p1 && a->wt_p2m && a->wt_p2s && a->wt_a[0] && a->wt_a[1] && a->wt_a[2] && a->wt_a4m && a->wt_a4s,
+               "bd_imagine_backward: missing weights");
+    BD_REQUIRE(a->start_feat && a->feat && a->prior_std && a->action && a->eps_action && a->eps_prior && a->sv_actor &&
+                   a->sv_act_stats && a->sv_x && a->sv_gates && a->sv_p && a->dfeat,
+               "bd_imagine_backward: missing forward tensors");
+    BD_REQUIRE(a->d_actor_pre && a->d_actor_out, "bd_imagine_backward: missing outputs");
+    const ImgDims d(a->Be, a->S, a->A, a->Hd);
+    const size_t lds = ((size_t)(6 * d.Kb_h + 3 * d.Kb_hd + 2 * d.Kb_s + 2 * d.Kb_a) * kFragFloats + 16 * a->S) * sizeof(float);
+    BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_imagine_backward: needs %zu B of LDS", lds);
+    if (lds > 64 * 1024 && allow_big_lds(imagine_bwd_kernel)) return -1;
+    hipLaunchKernelGGL(imagine_bwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);
+    BD_CHECK_LAUNCH("bd_imagine_backward");
+    return 0;
+}
+
+}  // extern "C"

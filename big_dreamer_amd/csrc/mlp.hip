@@ -1,0 +1,168 @@
+// mlp.hip -- dense chains (DenseModel / build_mlp: src/models.py:365-408, src/utils.py:368-404):
+// forward with saved activations, and the dgrad backward producing pre-activation gradients for
+// bd_wgrad.  One workgroup = 16*RT rows; the whole chain runs out of LDS, weights stream from L2.
+#include "bd_device.h"
+#include "bd_host.h"
+
+namespace bd {
+
+// ---- forward --------------------------------------------------------------------------------------
+template <int RT, int NI>
+__global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, int KbA) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int row0 = blockIdx.x * 16 * RT;
+    float* cur = smem;                                   // inputs of even layers
+    float* nxt = smem + (size_t)RT * KbA * kFragFloats;  // inputs of odd layers
+    load_tile_concat<RT>(cur, cdiv(a.w0 + a.w1, 16), row0, a.M, a.in0, a.ld0, a.w0, a.in1, a.ld1, a.w1);
+    __syncthreads();
+    for (int l = 0; l < a.n_layers; ++l) {
+        const bd_layer L = a.layer[l];
+        const bool last = (l == a.n_layers - 1);
+        const int Kb = cdiv(L.K, 16), Nb = cdiv(L.N, 16);
+        tile_linear<RT, NI>(cur, Kb, L.w, L.bias, L.N, [&](int rt, int nb, floatx4 acc) {
+            const int c = lane & 15, col = nb * 16 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * (lane >> 4) + r;
+                const int grow = row0 + rt * 16 + row;
+                const float v = act_apply(L.act, acc[r]);
+                if (!last) nxt[(rt * Nb + nb) * kFragFloats + ((c >> 2) * 16 + row) * 4 + (c & 3)] = v;
+                if (grow < a.M && col < L.N) {
+                    if (L.save) L.save[(size_t)grow * L.N + col] = v;
+                    if (last) a.out[(size_t)grow * a.ldo + col] = v;
+                }
+            }
+        });
+        __syncthreads();
+        float* t = cur; cur = nxt; nxt = t;
+    }
+}
+
+// ---- backward (dgrad chain) -------------------------------------------------------------------------
+template <int RT, int NI>
+__global__ __launch_bounds__(kThreads) void mlp_bwd_kernel(bd_mlp_bwd_args a, int KbA) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int row0 = blockIdx.x * 16 * RT;
+    float* cur = smem;
+    float* nxt = smem + (size_t)RT * KbA * kFragFloats;
+    // d(pre-activation) of the last layer
+    {
+        const bd_layer_bwd L = a.layer[a.n_layers - 1];
+        const int Kb = cdiv(L.N, 16), Kp = Kb * 16;
+        for (int idx = threadIdx.x; idx < RT * 16 * Kp; idx += blockDim.x) {
+            const int r = idx / Kp, k = idx - r * Kp;
+            const int grow = row0 + r;
+            float v = 0.f;
+            if (grow < a.M && k < L.N) {
+                v = a.dout[(size_t)grow * a.lddo + k] * a.dout_scale;
+                if (L.act) v *= elu_grad_from_out(L.saved[(size_t)grow * L.N + k]);
+                if (L.dpre) L.dpre[(size_t)grow * L.N + k] = v;
+            }
+            cur[(r >> 4) * Kb * kFragFloats + frag_idx(r & 15, k)] = v;
+        }
+    }
+    __syncthreads();
+    for (int l = a.n_layers - 1; l >= 1; --l) {
+        const bd_layer_bwd L = a.layer[l];       // contraction over this layer's outputs (N) -> its inputs (K)
+        const bd_layer_bwd P = a.layer[l - 1];   // whose outputs those inputs are
+        const int Kb = cdiv(L.N, 16), Nb = cdiv(L.K, 16);
+        tile_linear<RT, NI>(cur, Kb, L.wt, nullptr, L.K, [&](int rt, int nb, floatx4 acc) {
+            const int c = lane & 15, col = nb * 16 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * (lane >> 4) + r;
+                const int grow = row0 + rt * 16 + row;
+                float v = 0.f;
+                if (grow < a.M && col < P.N) {
+                    v = acc[r];
+                    if (P.act) v *= elu_grad_from_out(P.saved[(size_t)grow * P.N + col]);
+                    if (P.dpre) P.dpre[(size_t)grow * P.N + col] = v;
+                }
+                nxt[(rt * Nb + nb) * kFragFloats + ((c >> 2) * 16 + row) * 4 + (c & 3)] = v;
+            }
+        });
+        __syncthreads();
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    if (a.din0 != nullptr || a.din1 != nullptr) {
+        const bd_layer_bwd L = a.layer[0];
+        tile_linear<RT, NI>(cur, cdiv(L.N, 16), L.wt, nullptr, L.K, [&](int rt, int nb, floatx4 acc) {
+            const int col = nb * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int grow = row0 + rt * 16 + 4 * (lane >> 4) + r;
+                if (grow >= a.M) continue;
+                float* p = nullptr;
+                if (col < a.w0) { if (a.din0) p = a.din0 + (size_t)grow * a.ld0 + col; }
+                else if (col < a.w0 + a.w1) { if (a.din1) p = a.din1 + (size_t)grow * a.ld1 + (col - a.w0); }
+                if (p) *p = a.accumulate ? *p + acc[r] : acc[r];
+            }
+        });
+    }
+}
+
+template <class K, class Args>
+static int launch_chain(K kernel, const char* name, int M, int RT, int KbA, int KbB, hipStream_t s, const Args& args) {
+    const size_t lds = (size_t)RT * (KbA + KbB) * kFragFloats * sizeof(float);
+    BD_REQUIRE(lds <= (size_t)kMaxLds, "%s: chain needs %zu B of LDS (> %d)", name, lds, kMaxLds);
+    if (lds > 64 * 1024 && allow_big_lds(kernel)) return -1;
+    hipLaunchKernelGGL(kernel, dim3(cdiv(M, 16 * RT)), dim3(kThreads), lds, s, args, KbA);
+    BD_CHECK_LAUNCH(name);
+    return 0;
+}
+
+static int pick_rt(int M, int KbA, int KbB) {
+    const int tiles = cdiv(M, 16);
+    int rt = tiles >= 1024 ? 2 : 1;
+    while (rt > 1 && (size_t)rt * (KbA + KbB) * kFragFloats * sizeof(float) > 64 * 1024) rt >>= 1;
+    return rt;
+}
+
+}  // namespace bd
+
+extern "C" {
+
+int bd_mlp_forward(const bd_mlp_fwd_args* a, void* stream) {
+    using namespace bd;
+    BD_REQUIRE(a && a->M > 0 && a->n_layers >= 1 && a->n_layers <= BD_MAX_LAYERS, "bd_mlp_forward: bad M/n_layers");
+    BD_REQUIRE(a->in0 && a->w0 > 0 && a->ld0 >= a->w0, "bd_mlp_forward: bad input 0");
+    BD_REQUIRE(a->w1 == 0 || (a->in1 && a->ld1 >= a->w1), "bd_mlp_forward: bad input 1");
+    BD_REQUIRE(a->out && a->ldo >= a->layer[a->n_layers - 1].N, "bd_mlp_forward: bad output");
+    int KbA = 0, KbB = 0, k = a->w0 + a->w1;
+    for (int l = 0; l < a->n_layers; ++l) {
+        const bd_layer& L = a->layer[l];
+        BD_REQUIRE(L.w && L.N > 0 && L.K == k, "bd_mlp_forward: layer %d has K=%d, expected %d", l, L.K, k);
+        int& kb = (l & 1) ? KbB : KbA;
+        kb = cdiv(L.K, 16) > kb ? cdiv(L.K, 16) : kb;
+        k = L.N;
+    }
+    const int rt = pick_rt(a->M, KbA, KbB);
+    if (rt == 2) return launch_chain(mlp_fwd_kernel<2, 2>, "bd_mlp_forward", a->M, 2, KbA, KbB, (hipStream_t)stream, *a);
+    return launch_chain(mlp_fwd_kernel<1, 4>, "bd_mlp_forward", a->M, 1, KbA, KbB, (hipStream_t)stream, *a);
+}
+
+int bd_mlp_backward(const bd_mlp_bwd_args* a, void* stream) {
+    using namespace bd;
+    BD_REQUIRE(a && a->M > 0 && a->n_layers >= 1 && a->n_layers <= BD_MAX_LAYERS, "bd_mlp_backward: bad M/n_layers");
+    BD_REQUIRE(a->dout && a->lddo >= a->layer[a->n_layers - 1].N, "bd_mlp_backward: bad dout");
+    const bool want_din = a->din0 || a->din1;
+    // buffer A holds d(out) of layers L-1, L-3, ...; buffer B the others
+    int KbA = 0, KbB = 0;
+    for (int l = a->n_layers - 1, j = 0; l >= 0; --l, ++j) {
+        const bd_layer_bwd& L = a->layer[l];
+        BD_REQUIRE(L.N > 0 && L.K > 0, "bd_mlp_backward: layer %d has bad dims", l);
+        BD_REQUIRE(!L.act || L.saved, "bd_mlp_backward: layer %d needs its saved output", l);
+        BD_REQUIRE(l == 0 ? (!want_din || L.wt) : (L.wt != nullptr), "bd_mlp_backward: layer %d needs packed W^T", l);
+        BD_REQUIRE(l == 0 || a->layer[l - 1].N == L.K, "bd_mlp_backward: layer %d K mismatch", l);
+        int& kb = (j & 1) ? KbB : KbA;
+        kb = cdiv(L.N, 16) > kb ? cdiv(L.N, 16) : kb;
+    }
+    if (want_din) BD_REQUIRE(a->w0 + a->w1 == a->layer[0].K, "bd_mlp_backward: din widths != K of layer 0");
+    const int rt = pick_rt(a->M, KbA, KbB);
+    if (rt == 2) return launch_chain(mlp_bwd_kernel<2, 2>, "bd_mlp_backward", a->M, 2, KbA, KbB, (hipStream_t)stream, *a);
+    return launch_chain(mlp_bwd_kernel<1, 4>, "bd_mlp_backward", a->M, 1, KbA, KbB, (hipStream_t)stream, *a);
+}
+
+}  // extern "C"

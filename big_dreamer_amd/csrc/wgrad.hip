@@ -1,0 +1,118 @@
+// wgrad.hip -- weight gradients of a Linear layer over all rows of a pass:
+//   dW[N x K] = dpre^T[N x M] * act[M x K],   db[N] = sum_m dpre[m][n]
+// (what autograd's AddmmBackward computes for every nn.Linear on the path).  TN GEMM with a long
+// reduction (M = 2450 .. 34300 rows) and a small output, so the rows are split over workgroups; partial
+// tiles go to a slab workspace and are summed in fixed order (bitwise reproducible, no float atomics).
+// 64x64 output tile per workgroup, v_mfma_f32_32x32x2_f32 (exact fp32), operands staged through LDS.
+#include "bd_device.h"
+#include "bd_host.h"
+
+namespace bd {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr int kWT = 64;      // output tile edge
+constexpr int kWM = 32;      // rows per LDS stage
+
+__global__ __launch_bounds__(kThreads) void wgrad_kernel(const float* __restrict__ dpre, int ldp,
+                                                         const float* __restrict__ act, int lda, int M, int N, int K,
+                                                         int has_bias, int rows_per_split, float* __restrict__ ws) {
+    __shared__ float P[kWM][kWT];   // dpre chunk  [m][n]
+    __shared__ float A[kWM][kWT];   // act chunk   [m][k]
+    const int Kext = K + has_bias;
+    const int n0 = blockIdx.x * kWT, k0 = blockIdx.y * kWT;
+    const int m_begin = blockIdx.z * rows_per_split;
+    const int m_end = min(M, m_begin + rows_per_split);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;
+    floatx16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;   // each thread: column c, rows r0, r0+4, ...
+    for (int m0 = m_begin; m0 < m_end; m0 += kWM) {
+        float pv[kWM / 4], av[kWM / 4];
+#pragma unroll
+        for (int i = 0; i < kWM / 4; ++i) {
+            const int m = m0 + r0 + 4 * i;
+            const bool ok = m < m_end;
+            pv[i] = (ok && n0 + c < N) ? dpre[(size_t)m * ldp + n0 + c] : 0.f;
+            const int k = k0 + c;
+            av[i] = ok ? (k < K ? act[(size_t)m * lda + k] : (k == K && has_bias ? 1.f : 0.f)) : 0.f;
+        }
+        __syncthreads();   // previous stage's reads done
+#pragma unroll
+        for (int i = 0; i < kWM / 4; ++i) {
+            P[r0 + 4 * i][c] = pv[i];
+            A[r0 + 4 * i][c] = av[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < kWM / 2; ++s) {
+            const float a = P[2 * s + (lane >> 5)][wn + (lane & 31)];
+            const float b = A[2 * s + (lane >> 5)][wk + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    // D[i][j]: j = lane&31, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* slab = ws + (size_t)blockIdx.z * N * Kext;
+    const int k = k0 + wk + (lane & 31);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int n = n0 + wn + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (n < N && k < Kext) slab[(size_t)n * Kext + k] = acc[reg];
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int N, int K,
+                                                           int has_bias, float* __restrict__ dW, int ldw,
+                                                           float* __restrict__ db, int accumulate) {
+    const int Kext = K + has_bias;
+    const int total = N * Kext;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += ws[(size_t)z * total + e];
+        const int n = e / Kext, k = e - n * Kext;
+        float* dst = k < K ? dW + (size_t)n * ldw + k : db + n;
+        *dst = accumulate ? *dst + s : s;
+    }
+}
+
+static void wgrad_plan(int M, int N, int K, int has_bias, int* splits, int* rows_per) {
+    const int tiles = cdiv(N, kWT) * cdiv(K + has_bias, kWT);
+    int s = 1024 / tiles;
+    const int max_s = cdiv(M, 2 * kWM);
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    int rp = cdiv(cdiv(M, s), kWM) * kWM;
+    *rows_per = rp;
+    *splits = cdiv(M, rp);
+}
+
+}  // namespace bd
+
+extern "C" {
+
+size_t bd_wgrad_ws_floats(int M, int N, int K) {
+    int s, rp;
+    bd::wgrad_plan(M, N, K, 1, &s, &rp);
+    return (size_t)s * N * (K + 1);
+}
+
+int bd_wgrad(const float* dpre, int ldp, const float* act, int lda, int M, int N, int K, float* dW, int ldw,
+             float* db, int accumulate, float* ws, void* stream) {
+    using namespace bd;
+    BD_REQUIRE(dpre && act && dW && ws && M > 0 && N > 0 && K > 0, "bd_wgrad: bad arguments");
+    BD_REQUIRE(ldp >= N && lda >= K && ldw >= K, "bd_wgrad: leading dimension too small");
+    const int hb = db != nullptr;
+    int splits, rows_per;
+    wgrad_plan(M, N, K, hb, &splits, &rows_per);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(cdiv(N, kWT), cdiv(K + hb, kWT), splits), dim3(kThreads), 0,
+                       (hipStream_t)stream, dpre, ldp, act, lda, M, N, K, hb, rows_per, ws);
+    BD_CHECK_LAUNCH("bd_wgrad");
+    const int total = N * (K + hb);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256) < 1024 ? cdiv(total, 256) : 1024), dim3(256), 0,
+                       (hipStream_t)stream, ws, splits, N, K, hb, dW, ldw, db, accumulate);
+    BD_CHECK_LAUNCH("bd_wgrad(reduce)");
+    return 0;
+}
+
+}  // extern "C"

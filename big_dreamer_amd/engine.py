@@ -1,0 +1,546 @@
+"""DreamerEngine -- host-side schedule of the MI355X-native Dreamer training step.
+
+This is plumbing around the C ABI (``include/bigdreamer_hip.h``): it owns the flat fp32 parameter /
+gradient / Adam buffers (one per optimiser, reference order ``src/dreamer.py:160-165``), the packed
+weight copies the kernels read, the saved-activation workspaces, and issues the kernels of one
+``Dreamer.train_step`` (``src/dreamer.py:253-393``) in dependency order on the current stream.  All
+arithmetic happens in the HIP library; torch supplies device memory, streams, the noise generator
+and (multi-GPU) ``torch.distributed`` all-reduces over RCCL.
+
+No autograd graph is built: the backward schedule is explicit (the reference's three ``backward()`` calls
+become observe/imagine/MLP backward kernels + weight-gradient GEMMs).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _cabi as cabi
+from .synth import DENSE_LAYERS, MODEL_MODULES, Dims, param_shapes
+
+lib = cabi.lib
+ptr = cabi.ptr
+
+DEFAULT_HP = dict(
+    kl_balance=0.8, kl_loss_weight=0.1, free_nats=3.0, grad_clip_norm=100.0, discount=0.995, disclam=0.95,
+    model_learning_rate=2e-4, actor_learning_rate=4e-5, value_learning_rate=1e-4, adam_epsilon=1e-5,
+    weight_decay=1e-6, entropy_weight=1e-5, polyak_avg=1.0, min_std_dev=0.1,
+)
+
+# actor constants (src/models.py:479-503)
+ACT_RAW_INIT_STD = float(torch.log(torch.exp(torch.tensor(5.0)) - 1))
+ACT_MIN_STD = 1e-4
+ACT_MEAN_SCALE = 5.0
+
+# scalar-board slots (raw sums; see include/bigdreamer_hip.h "losses")
+SLOT_OBS, SLOT_REW, SLOT_KL, SLOT_RET, SLOT_ENT, SLOT_VAL, SLOT_GN_MODEL, SLOT_GN_ACTOR, SLOT_GN_CRITIC = range(9)
+N_SLOTS = 16
+
+
+class ParamGroup:
+    """Flat parameter / gradient / Adam-moment buffers of one optimiser, with named views."""
+
+    def __init__(self, specs: List[Tuple[str, str, Tuple[int, ...]]], device, with_opt: bool = True):
+        self.specs = specs
+        n = sum(int(np.prod(s)) for _, _, s in specs)
+        self.numel = n
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=device) if with_opt else None
+        self.m = torch.zeros(n, dtype=torch.float32, device=device) if with_opt else None
+        self.v = torch.zeros(n, dtype=torch.float32, device=device) if with_opt else None
+        self.step = 0
+        self.p: Dict[Tuple[str, str], torch.Tensor] = {}
+        self.g: Dict[Tuple[str, str], torch.Tensor] = {}
+        off = 0
+        for mod, name, shape in specs:
+            k = int(np.prod(shape))
+            self.p[(mod, name)] = self.flat[off:off + k].view(shape)
+            if with_opt:
+                self.g[(mod, name)] = self.grad[off:off + k].view(shape)
+            off += k
+
+
+class DreamerEngine:
+    def __init__(self, dims: Dims, hp: Optional[dict] = None, device="cuda", params: Optional[dict] = None,
+                 world_size: int = 1, process_group=None):
+        self.d = dims
+        self.hp = dict(DEFAULT_HP)
+        if hp:
+            self.hp.update({k: v for k, v in hp.items() if k in self.hp})
+        self.dev = torch.device(device)
+        assert self.dev.type == "cuda", "the HIP path needs a GPU (there is no CPU fallback)"
+        self.world_size = world_size
+        self.pg = process_group
+        d = dims
+        shapes = param_shapes(d)
+        self.groups = {
+            "model": ParamGroup([(m, n, s) for m in MODEL_MODULES for n, s in shapes[m]], self.dev),
+            "actor": ParamGroup([("actor", n, s) for n, s in shapes["actor"]], self.dev),
+            "critic": ParamGroup([("critic", n, s) for n, s in shapes["critic"]], self.dev),
+            "critic_target": ParamGroup([("critic_target", n, s) for n, s in shapes["critic"]], self.dev, False),
+        }
+        self._mod_group = {m: "model" for m in MODEL_MODULES}
+        self._mod_group.update(actor="actor", critic="critic", critic_target="critic_target")
+        if params is not None:
+            self.load_params(params)
+        self.scalars = torch.zeros(N_SLOTS, dtype=torch.float32, device=self.dev)
+        self.red_ws = torch.zeros(int(lib.bd_reduce_ws_floats()), dtype=torch.float32, device=self.dev)
+        self._wgrad_ws = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self._buf: Dict[str, torch.Tensor] = {}
+        self._build_pack_tables()
+        for g in ("model", "actor", "critic", "critic_target"):
+            self.pack(g)
+
+    # ------------------------------------------------------------------------------------------ params
+    def W(self, mod: str, name: str) -> torch.Tensor:
+        return self.groups[self._mod_group[mod]].p[(mod, name)]
+
+    def G(self, mod: str, name: str) -> torch.Tensor:
+        return self.groups[self._mod_group[mod]].g[(mod, name)]
+
+    def load_params(self, params: dict) -> None:
+        for mod, sd in params.items():
+            for name, v in sd.items():
+                self.W(mod, name).copy_(torch.as_tensor(np.asarray(v), dtype=torch.float32))
+
+    def state_dict(self, mod: str) -> Dict[str, torch.Tensor]:
+        g = self.groups[self._mod_group[mod]]
+        return {n: g.p[(m, n)] for (m, n, _) in g.specs if m == mod}
+
+    def buf(self, name: str, *shape) -> torch.Tensor:
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+            self._buf[name] = t
+        return t
+
+    # ------------------------------------------------------------------------------------------ packing
+    def _build_pack_tables(self) -> None:
+        d = self.d
+        Be, S, A, Hd = d.Be, d.S, d.A, d.Hd
+        ent: Dict[str, List[Tuple[str, torch.Tensor, bool]]] = {g: [] for g in ("model", "actor", "critic", "critic_target")}
+
+        def add(group, key, view, fwd=True, tr=False):
+            if fwd:
+                ent[group].append((key, view, False))
+            if tr:
+                ent[group].append((key + ".T", view, True))
+
+        tm = lambda n: self.W("transition_model", n)
+        We = tm("fc_embed_state_action.0.weight")
+        add("model", "embed_s", We[:, :S], tr=True)
+        add("model", "embed_a", We[:, S:], tr=True)
+        for gi, gname in enumerate("rzn"):
+            add("model", f"i{gname}", tm("rnn.weight_ih")[gi * Be:(gi + 1) * Be], tr=True)
+            add("model", f"h{gname}", tm("rnn.weight_hh")[gi * Be:(gi + 1) * Be], tr=True)
+        add("model", "p1", tm("belief_prior.model.0.weight"), tr=True)
+        Wp2 = tm("belief_prior.model.2.weight")
+        add("model", "p2", Wp2, tr=True)
+        add("model", "p2m", Wp2[:S], tr=True)
+        add("model", "p2s", Wp2[S:], tr=True)
+        Wq1 = tm("belief_posterior.model.0.weight")
+        add("model", "q1h", Wq1[:, :Be], tr=True)
+        add("model", "q1e", Wq1[:, Be:], tr=True)
+        Wq2 = tm("belief_posterior.model.2.weight")
+        add("model", "q2m", Wq2[:S], tr=True)
+        add("model", "q2s", Wq2[S:], tr=True)
+        for l in range(DENSE_LAYERS + 1):
+            add("model", f"enc{l}", self.W("encoder", f"model.{2 * l}.weight"), tr=(l > 0))
+            add("model", f"obs{l}", self.W("observation_model", f"model.{2 * l}.weight"), tr=True)
+            add("model", f"rew{l}", self.W("reward_model", f"model.{2 * l}.weight"), tr=True)
+            add("critic", f"cri{l}", self.W("critic", f"model.{2 * l}.weight"), tr=(l > 0))
+            add("critic_target", f"tgt{l}", self.W("critic_target", f"model.{2 * l}.weight"), tr=True)
+        Wa0 = self.W("actor", "model.0.weight")
+        add("actor", "a0h", Wa0[:, :Be])
+        add("actor", "a0s", Wa0[:, Be:])
+        for l in range(1, DENSE_LAYERS):
+            add("actor", f"a{l}", self.W("actor", f"model.{2 * l}.weight"), tr=True)
+        Wa4 = self.W("actor", f"model.{2 * DENSE_LAYERS}.weight")
+        add("actor", "a4m", Wa4[:A], tr=True)
+        add("actor", "a4s", Wa4[A:], tr=True)
+
+        self.pk: Dict[str, torch.Tensor] = {}
+        self._pack_tables = {}
+        for group, lst in ent.items():
+            total = sum(cabi.packed_floats(*(v.shape if not tr else v.shape[::-1])) for _, v, tr in lst)
+            store = torch.zeros(total, dtype=torch.float32, device=self.dev)
+            descs = (cabi.PackDesc * len(lst))()
+            off = 0
+            for i, (key, v, tr) in enumerate(lst):
+                N, K = v.shape
+                n = cabi.packed_floats(N, K)   # same count for the transpose
+                self.pk[key] = store[off:off + n]
+                descs[i] = cabi.PackDesc(v.data_ptr(), self.pk[key].data_ptr(), v.stride(0), N, K, int(tr))
+                off += n
+            raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.dev)
+            self._pack_tables[group] = (raw, len(lst), store)
+
+    def pack(self, group: str) -> None:
+        raw, n, _ = self._pack_tables[group]
+        cabi.check(lib.bd_pack_weights(raw.data_ptr(), n, cabi.stream()))
+
+    # ------------------------------------------------------------------------------------------ kernels
+    def _dense_spec(self, mod: str, prefix: str, in_width: int, out_width: int):
+        """[(packed W key, bias view, N, K, act)] for a DenseModel (4 hidden ELU layers + linear)."""
+        sizes = [in_width] + [self.d.Hd] * DENSE_LAYERS + [out_width]
+        return [(f"{prefix}{l}", self.W(mod, f"model.{2 * l}.bias"), sizes[l + 1], sizes[l],
+                 cabi.ACT_ELU if l < DENSE_LAYERS else cabi.ACT_NONE) for l in range(DENSE_LAYERS + 1)]
+
+    def mlp_forward(self, M, in0, ld0, w0, layers, saves, out, ldo, in1=None, ld1=0, w1=0) -> None:
+        a = cabi.MlpFwdArgs()
+        a.M, a.in0, a.ld0, a.w0 = M, ptr(in0), ld0, w0
+        a.in1, a.ld1, a.w1 = ptr(in1), ld1, w1
+        a.n_layers = len(layers)
+        for i, (key, bias, N, K, act) in enumerate(layers):
+            a.layer[i] = cabi.Layer(ptr(self.pk[key]), ptr(bias), N, K, act, ptr(saves[i]) if saves else None)
+        a.out, a.ldo = ptr(out), ldo
+        cabi.check(lib.bd_mlp_forward(C.byref(a), cabi.stream()))
+
+    def mlp_backward(self, M, dout, lddo, layers, saves, dpres, din0=None, ld0=0, w0=0, din1=None, ld1=0, w1=0,
+                     accumulate=False, dout_scale=1.0) -> None:
+        a = cabi.MlpBwdArgs()
+        a.M, a.dout, a.lddo, a.dout_scale = M, ptr(dout), lddo, dout_scale
+        a.n_layers = len(layers)
+        for i, (key, _bias, N, K, act) in enumerate(layers):
+            wt = self.pk.get(key + ".T")
+            a.layer[i] = cabi.LayerBwd(ptr(wt) if wt is not None else None,
+                                       ptr(saves[i]) if (saves and saves[i] is not None) else None, N, K, act,
+                                       ptr(dpres[i]) if (dpres and dpres[i] is not None) else None)
+        a.din0, a.ld0, a.w0 = ptr(din0), ld0, w0
+        a.din1, a.ld1, a.w1 = ptr(din1), ld1, w1
+        a.accumulate = int(accumulate)
+        cabi.check(lib.bd_mlp_backward(C.byref(a), cabi.stream()))
+
+    def wgrad(self, dpre, ldp, act, lda, M, N, K, dW, ldw, db=None, accumulate=False) -> None:
+        need = int(lib.bd_wgrad_ws_floats(M, N, K))
+        if self._wgrad_ws.numel() < need:
+            self._wgrad_ws = torch.zeros(need, dtype=torch.float32, device=self.dev)
+        cabi.check(lib.bd_wgrad(ptr(dpre), ldp, ptr(act), lda, M, N, K, ptr(dW), ldw, ptr(db), int(accumulate),
+                                ptr(self._wgrad_ws), cabi.stream()))
+
+    def _dense_wgrads(self, mod: str, M: int, dpres, inp, ld_in, saves, sizes) -> None:
+        """Weight/bias gradients of a DenseModel from its pre-activation gradients."""
+        for l in range(len(sizes) - 1):
+            act, lda = (inp, ld_in) if l == 0 else (saves[l - 1], sizes[l])
+            self.wgrad(dpres[l], sizes[l + 1], act, lda, M, sizes[l + 1], sizes[l],
+                       self.G(mod, f"model.{2 * l}.weight"), sizes[l], self.G(mod, f"model.{2 * l}.bias"))
+
+    def _allreduce(self, t: torch.Tensor) -> None:
+        if self.world_size > 1:
+            torch.distributed.all_reduce(t, group=self.pg)
+
+    def optimizer_step(self, group: str, slot: int, lr: float) -> None:
+        g = self.groups[group]
+        self._allreduce(g.grad)       # grads already carry 1/global-count: SUM over ranks = global-mean gradient
+        g.step += 1
+        hp = self.hp
+        cabi.check(lib.bd_sumsq(ptr(g.grad), g.numel, ptr(self.scalars), slot, ptr(self.red_ws), cabi.stream()))
+        cabi.check(lib.bd_adam_step(ptr(g.flat), ptr(g.grad), ptr(g.m), ptr(g.v), g.numel, lr, 0.9, 0.999,
+                                    hp["adam_epsilon"], hp["weight_decay"], g.step, hp["grad_clip_norm"],
+                                    ptr(self.scalars), slot, cabi.stream()))
+        self.pack(group)
+
+    def update_critic(self) -> None:
+        """polyak_update(critic_target, critic, polyak_avg) (src/dreamer.py:423-427)."""
+        t, s = self.groups["critic_target"], self.groups["critic"]
+        cabi.check(lib.bd_polyak(ptr(t.flat), ptr(s.flat), t.numel, float(self.hp["polyak_avg"]), cabi.stream()))
+        self.pack("critic_target")
+
+    # ------------------------------------------------------------------------------------------ forward pieces
+    def encode(self, obs2d: torch.Tensor, M: int, save: bool = True):
+        """Encoder DenseModel (src/planet.py:195-200) + hoisted embedding half of the posterior's first
+        layer.  Returns (embeddings [M x E], pre_emb [M x Hd])."""
+        d = self.d
+        layers = self._dense_spec("encoder", "enc", d.O, d.E) + [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)]
+        acts = [self.buf(f"enc_act{l}", M, d.Hd) for l in range(DENSE_LAYERS)]
+        emb = self.buf("emb", M, d.E)
+        pre = self.buf("pre_emb", M, d.Hd)
+        self.mlp_forward(M, obs2d, d.O, d.O, layers, acts + [emb, None], pre, d.Hd)
+        return emb, pre
+
+    def observe(self, actions, nonterm, pre_emb, eps_post, init_belief, init_state, T: int, B: int, save: bool = True):
+        """TransitionModel.forward recurrence (posterior path).  Returns feat [T*B x (Be+S)], post_mean, post_std."""
+        d, pk = self.d, self.pk
+        tm = lambda n: self.W("transition_model", n)
+        M = T * B
+        a = cabi.ObserveFwdArgs()
+        a.T, a.B, a.Be, a.S, a.A, a.Hd = T, B, d.Be, d.S, d.A, d.Hd
+        a.w_embed_s, a.w_embed_a, a.b_embed = ptr(pk["embed_s"]), ptr(pk["embed_a"]), ptr(tm("fc_embed_state_action.0.bias"))
+        a.w_ir, a.w_iz, a.w_in = ptr(pk["ir"]), ptr(pk["iz"]), ptr(pk["in"])
+        a.w_hr, a.w_hz, a.w_hn = ptr(pk["hr"]), ptr(pk["hz"]), ptr(pk["hn"])
+        a.b_ih, a.b_hh = ptr(tm("rnn.bias_ih")), ptr(tm("rnn.bias_hh"))
+        a.w_q1h, a.b_q1 = ptr(pk["q1h"]), ptr(tm("belief_posterior.model.0.bias"))
+        a.w_q2m, a.w_q2s, a.b_q2 = ptr(pk["q2m"]), ptr(pk["q2s"]), ptr(tm("belief_posterior.model.2.bias"))
+        a.init_belief, a.init_state, a.actions = ptr(init_belief), ptr(init_state), ptr(actions)
+        a.nonterm, a.pre_emb, a.eps_post = ptr(nonterm), ptr(pre_emb), ptr(eps_post)
+        a.min_std = self.hp["min_std_dev"]
+        feat = self.buf("feat", M, d.Be + d.S)
+        qm, qs = self.buf("post_mean", M, d.S), self.buf("post_std", M, d.S)
+        a.feat, a.post_mean, a.post_std = ptr(feat), ptr(qm), ptr(qs)
+        if save:
+            a.sv_s, a.sv_x = ptr(self.buf("sv_s", M, d.S)), ptr(self.buf("sv_x", M, d.Be))
+            a.sv_gates, a.sv_q = ptr(self.buf("sv_gates", M, 4 * d.Be)), ptr(self.buf("sv_q", M, d.Hd))
+        cabi.check(lib.bd_observe_forward(C.byref(a), cabi.stream()))
+        return feat, qm, qs
+
+    def prior_head(self, feat, M: int, eps):
+        """belief_prior on all beliefs at once (src/models.py:256): returns state, mean, std [M x S]."""
+        d = self.d
+        tm = lambda n: self.W("transition_model", n)
+        layers = [("p1", tm("belief_prior.model.0.bias"), d.Hd, d.Be, cabi.ACT_ELU),
+                  ("p2", tm("belief_prior.model.2.bias"), 2 * d.S, d.Hd, cabi.ACT_NONE)]
+        hid, out = self.buf("p_hid", M, d.Hd), self.buf("p_out", M, 2 * d.S)
+        self.mlp_forward(M, feat, d.Be + d.S, d.Be, layers, [hid, None], out, 2 * d.S)
+        pm, ps, pst = self.buf("prior_mean", M, d.S), self.buf("prior_std", M, d.S), self.buf("prior_state", M, d.S)
+        cabi.check(lib.bd_gauss_head_forward(ptr(out), ptr(eps), M, d.S, self.hp["min_std_dev"], ptr(pm), ptr(ps),
+                                             ptr(pst), cabi.stream()))
+        return pst, pm, ps
+
+    def dense_forward(self, mod: str, prefix: str, tag: str, x, ldx: int, M: int, out_width: int):
+        d = self.d
+        layers = self._dense_spec(mod, prefix, ldx, out_width)
+        acts = [self.buf(f"{tag}_act{l}", M, d.Hd) for l in range(DENSE_LAYERS)]
+        out = self.buf(f"{tag}_out", M, out_width)
+        self.mlp_forward(M, x, ldx, ldx, layers, acts + [None], out, out_width)
+        return out, acts, layers
+
+    def imagine(self, start_feat, N: int, Hm: int, noise, save: bool = True):
+        d, pk = self.d, self.pk
+        tm = lambda n: self.W("transition_model", n)
+        ac = lambda n: self.W("actor", n)
+        Mi = Hm * N
+        a = cabi.ImagineFwdArgs()
+        a.N, a.Hm, a.Be, a.S, a.A, a.Hd, a.n_samples = N, Hm, d.Be, d.S, d.A, d.Hd, d.n_entropy
+        a.w_embed_s, a.w_embed_a, a.b_embed = ptr(pk["embed_s"]), ptr(pk["embed_a"]), ptr(tm("fc_embed_state_action.0.bias"))
+        a.w_ir, a.w_iz, a.w_in = ptr(pk["ir"]), ptr(pk["iz"]), ptr(pk["in"])
+        a.w_hr, a.w_hz, a.w_hn = ptr(pk["hr"]), ptr(pk["hz"]), ptr(pk["hn"])
+        a.b_ih, a.b_hh = ptr(tm("rnn.bias_ih")), ptr(tm("rnn.bias_hh"))
+        a.w_p1, a.b_p1 = ptr(pk["p1"]), ptr(tm("belief_prior.model.0.bias"))
+        a.w_p2m, a.w_p2s, a.b_p2 = ptr(pk["p2m"]), ptr(pk["p2s"]), ptr(tm("belief_prior.model.2.bias"))
+        a.w_a0h, a.w_a0s = ptr(pk["a0h"]), ptr(pk["a0s"])
+        for l in range(1, DENSE_LAYERS):
+            a.w_a[l - 1] = ptr(pk[f"a{l}"])
+        for l in range(DENSE_LAYERS):
+            a.b_a[l] = ptr(ac(f"model.{2 * l}.bias"))
+        a.w_a4m, a.w_a4s, a.b_a4 = ptr(pk["a4m"]), ptr(pk["a4s"]), ptr(ac(f"model.{2 * DENSE_LAYERS}.bias"))
+        a.start_feat = ptr(start_feat)
+        a.eps_action, a.eps_entropy, a.eps_prior = ptr(noise["action"]), ptr(noise["entropy"]), ptr(noise["img_prior"])
+        a.min_std, a.act_raw_init_std = self.hp["min_std_dev"], ACT_RAW_INIT_STD
+        a.act_min_std, a.act_mean_scale = ACT_MIN_STD, ACT_MEAN_SCALE
+        ifeat = self.buf("ifeat", Mi, d.Be + d.S)
+        a.feat = ptr(ifeat)
+        a.prior_mean, a.prior_std = ptr(self.buf("iprior_mean", Mi, d.S)), ptr(self.buf("iprior_std", Mi, d.S))
+        ent, act = self.buf("entropy", Mi), self.buf("action", Mi, d.A)
+        a.entropy, a.action = ptr(ent), ptr(act)
+        if save:
+            a.sv_actor = ptr(self.buf("sv_actor", DENSE_LAYERS, Mi, d.Hd))
+            a.sv_act_stats = ptr(self.buf("sv_act_stats", Mi, 4 * d.A))
+            a.sv_x, a.sv_gates = ptr(self.buf("isv_x", Mi, d.Be)), ptr(self.buf("isv_gates", Mi, 4 * d.Be))
+            a.sv_p = ptr(self.buf("isv_p", Mi, d.Hd))
+        cabi.check(lib.bd_imagine_forward(C.byref(a), cabi.stream()))
+        return ifeat, ent, act
+
+    # ------------------------------------------------------------------------------------------ train step
+    def make_noise(self, B: int) -> Dict[str, torch.Tensor]:
+        """On-device standard-normal noise for one step (perf mode; parity tests pass explicit arrays)."""
+        d = self.d
+        T, N, Hm = d.T, d.T * B, d.Hm
+        shapes = dict(obs_prior=(T, B, d.S), obs_post=(T, B, d.S), action=(Hm, N, d.A),
+                      entropy=(Hm, d.n_entropy, N, d.A), img_prior=(Hm, N, d.S))
+        return {k: self.buf("noise_" + k, *s).normal_() for k, s in shapes.items()}
+
+    def train_step(self, batch: Dict[str, torch.Tensor], noise: Optional[Dict[str, torch.Tensor]] = None,
+                   sync_logs: bool = True) -> Dict[str, float]:
+        """One Dreamer.train_step (src/dreamer.py:253-393) on this rank's batch shard.
+
+        batch: observations (L,B,O), actions (L,B,A), rewards (L,B), nonterminals (L,B,1) -- device fp32,
+        contiguous, time-major as ExperienceReplay.sample returns them (src/memory.py:87-104)."""
+        d, hp = self.d, self.hp
+        obs, actions, rewards, nonterm = (batch[k] for k in ("observations", "actions", "rewards", "nonterminals"))
+        L, B = obs.shape[0], obs.shape[1]
+        T, Hm = L - 1, d.Hm
+        N = T * B
+        Mi = Hm * N
+        F = d.Be + d.S
+        W = self.world_size
+        if noise is None:
+            noise = self.make_noise(B)
+        st = cabi.stream()
+        sc, ws = ptr(self.scalars), ptr(self.red_ws)
+
+        # ======================= dynamics learning (dreamer.py:263-302) =======================
+        obs_t = obs[1:].reshape(N, d.O)                     # targets and encoder input
+        emb, pre_emb = self.encode(obs_t, N)
+        init_belief = self.buf("init_belief", B, d.Be).zero_()
+        init_state = self.buf("init_state", B, d.S).zero_()
+        feat, qm, qs = self.observe(actions[:-1], nonterm[:-1], pre_emb, noise["obs_post"], init_belief, init_state, T, B)
+        _, pm, ps = self.prior_head(feat, N, noise["obs_prior"])
+        om_out, om_acts, om_layers = self.dense_forward("observation_model", "obs", "om", feat, F, N, d.O)
+        rw_out, rw_acts, rw_layers = self.dense_forward("reward_model", "rew", "rw", feat, F, N, 1)
+
+        inv_rows = 1.0 / (N * W)
+        d_om, d_rw = self.buf("d_om_out", N, d.O), self.buf("d_rw_out", N, 1)
+        cabi.check(lib.bd_normal_nll(ptr(om_out), d.O, ptr(obs_t), d.O, N, d.O, inv_rows, ptr(d_om), d.O, sc, SLOT_OBS, ws, st))
+        cabi.check(lib.bd_normal_nll(ptr(rw_out), 1, ptr(rewards[:-1]), 1, N, 1, inv_rows, ptr(d_rw), 1, sc, SLOT_REW, ws, st))
+        sum_form = int(hp["kl_balance"] == -1)
+        cabi.check(lib.bd_kl_forward(ptr(qm), ptr(qs), ptr(pm), ptr(ps), N, d.S, hp["free_nats"], sum_form, sc, SLOT_KL, ws, st))
+        if W > 1 and not sum_form:                          # the free-nats clamp acts on the GLOBAL mean
+            self._kl_local = self.scalars[SLOT_KL:SLOT_KL + 1].clone()
+            self._allreduce(self.scalars[SLOT_KL:SLOT_KL + 1])
+        dqm, dqs = self.buf("dqm", N, d.S), self.buf("dqs", N, d.S)
+        dpm, dps = self.buf("dpm", N, d.S), self.buf("dps", N, d.S)
+        kl_inv = 1.0 / (N * d.S * W) if not sum_form else 1.0 / (N * W)
+        cabi.check(lib.bd_kl_backward(ptr(qm), ptr(qs), ptr(pm), ptr(ps), N, d.S, hp["free_nats"], hp["kl_balance"],
+                                      hp["kl_loss_weight"] * (1.0 / W if sum_form else 1.0), kl_inv, sc, SLOT_KL,
+                                      ptr(dqm), ptr(dqs), ptr(dpm), ptr(dps), st))
+
+        # ---- backward of the world model ----
+        dfeat = self.buf("dfeat", N, F)
+        om_dpre = [self.buf(f"om_dpre{l}", N, d.Hd) for l in range(DENSE_LAYERS)] + [d_om]
+        rw_dpre = [self.buf(f"rw_dpre{l}", N, d.Hd) for l in range(DENSE_LAYERS)] + [d_rw]
+        self.mlp_backward(N, d_om, d.O, om_layers, om_acts + [None], om_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F)
+        self.mlp_backward(N, d_rw, 1, rw_layers, rw_acts + [None], rw_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F,
+                          accumulate=True)
+        # prior head: KL gradient on (mean, std) -> belief part of dfeat
+        p_out, p_hid = self._buf["p_out"], self._buf["p_hid"]
+        d_p_out, d_p_hid = self.buf("d_p_out", N, 2 * d.S), self.buf("d_p_hid", N, d.Hd)
+        cabi.check(lib.bd_gauss_head_backward(ptr(p_out), None, None, ptr(dpm), ptr(dps), N, d.S, ptr(d_p_out), st))
+        tm = lambda n: self.W("transition_model", n)
+        p_layers = [("p1", None, d.Hd, d.Be, cabi.ACT_ELU), ("p2", None, 2 * d.S, d.Hd, cabi.ACT_NONE)]
+        self.mlp_backward(N, d_p_out, 2 * d.S, p_layers, [p_hid, None], [d_p_hid, None], din0=dfeat, ld0=F, w0=d.Be,
+                          accumulate=True)
+        # recurrence
+        b = cabi.ObserveBwdArgs()
+        pk = self.pk
+        b.T, b.B, b.Be, b.S, b.A, b.Hd = T, B, d.Be, d.S, d.A, d.Hd
+        b.wt_embed_s = ptr(pk["embed_s.T"])
+        b.wt_ir, b.wt_iz, b.wt_in = ptr(pk["ir.T"]), ptr(pk["iz.T"]), ptr(pk["in.T"])
+        b.wt_hr, b.wt_hz, b.wt_hn = ptr(pk["hr.T"]), ptr(pk["hz.T"]), ptr(pk["hn.T"])
+        b.wt_q1h, b.wt_q2m, b.wt_q2s = ptr(pk["q1h.T"]), ptr(pk["q2m.T"]), ptr(pk["q2s.T"])
+        b.init_belief, b.nonterm, b.eps_post = ptr(init_belief), ptr(nonterm[:-1]), ptr(noise["obs_post"])
+        b.feat, b.post_std = ptr(feat), ptr(qs)
+        b.sv_x, b.sv_gates, b.sv_q = ptr(self._buf["sv_x"]), ptr(self._buf["sv_gates"]), ptr(self._buf["sv_q"])
+        b.dfeat, b.dpost_mean, b.dpost_std = ptr(dfeat), ptr(dqm), ptr(dqs)
+        b.min_std = hp["min_std_dev"]
+        d_e, d_gi, d_gh = self.buf("d_embed_pre", N, d.Be), self.buf("d_gi", N, 3 * d.Be), self.buf("d_gh", N, 3 * d.Be)
+        d_q1, d_q2 = self.buf("d_q1_pre", N, d.Hd), self.buf("d_q2_out", N, 2 * d.S)
+        b.d_embed_pre, b.d_gi, b.d_gh, b.d_q1_pre, b.d_q2_out = ptr(d_e), ptr(d_gi), ptr(d_gh), ptr(d_q1), ptr(d_q2)
+        cabi.check(lib.bd_observe_backward(C.byref(b), st))
+        # encoder (+ hoisted projection as its last layer)
+        enc_layers = self._dense_spec("encoder", "enc", d.O, d.E) + [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)]
+        enc_acts = [self._buf[f"enc_act{l}"] for l in range(DENSE_LAYERS)]
+        enc_dpre = [self.buf(f"enc_dpre{l}", N, d.Hd) for l in range(DENSE_LAYERS)] + [self.buf("d_emb", N, d.E)]
+        self.mlp_backward(N, d_q1, d.Hd, enc_layers, enc_acts + [None, None], enc_dpre + [None])
+
+        # ---- weight gradients (into the flat model gradient buffer) ----
+        Gt = lambda n: self.G("transition_model", n)
+        self.wgrad(d_gi, 3 * d.Be, self._buf["sv_x"], d.Be, N, 3 * d.Be, d.Be, Gt("rnn.weight_ih"), d.Be, Gt("rnn.bias_ih"))
+        self.wgrad(d_gh, 3 * d.Be, init_belief, d.Be, B, 3 * d.Be, d.Be, Gt("rnn.weight_hh"), d.Be, Gt("rnn.bias_hh"))
+        if T > 1:   # previous belief of step t >= 1 is the belief part of feat[t-1]
+            self.wgrad(d_gh[B:], 3 * d.Be, feat, F, N - B, 3 * d.Be, d.Be, Gt("rnn.weight_hh"), d.Be, Gt("rnn.bias_hh"),
+                       accumulate=True)
+        gWe = Gt("fc_embed_state_action.0.weight")
+        self.wgrad(d_e, d.Be, self._buf["sv_s"], d.S, N, d.Be, d.S, gWe, d.S + d.A, Gt("fc_embed_state_action.0.bias"))
+        self.wgrad(d_e, d.Be, actions[:-1], d.A, N, d.Be, d.A, gWe[:, d.S:], d.S + d.A)
+        self.wgrad(d_p_hid, d.Hd, feat, F, N, d.Hd, d.Be, Gt("belief_prior.model.0.weight"), d.Be, Gt("belief_prior.model.0.bias"))
+        self.wgrad(d_p_out, 2 * d.S, p_hid, d.Hd, N, 2 * d.S, d.Hd, Gt("belief_prior.model.2.weight"), d.Hd,
+                   Gt("belief_prior.model.2.bias"))
+        gWq1 = Gt("belief_posterior.model.0.weight")
+        self.wgrad(d_q1, d.Hd, feat, F, N, d.Hd, d.Be, gWq1, d.Be + d.E, Gt("belief_posterior.model.0.bias"))
+        self.wgrad(d_q1, d.Hd, emb, d.E, N, d.Hd, d.E, gWq1[:, d.Be:], d.Be + d.E)
+        self.wgrad(d_q2, 2 * d.S, self._buf["sv_q"], d.Hd, N, 2 * d.S, d.Hd, Gt("belief_posterior.model.2.weight"), d.Hd,
+                   Gt("belief_posterior.model.2.bias"))
+        dense_sizes = lambda i, o: [i] + [d.Hd] * DENSE_LAYERS + [o]
+        self._dense_wgrads("observation_model", N, om_dpre, feat, F, om_acts, dense_sizes(F, d.O))
+        self._dense_wgrads("reward_model", N, rw_dpre, feat, F, rw_acts, dense_sizes(F, 1))
+        self._dense_wgrads("encoder", N, enc_dpre, obs_t, d.O, enc_acts, dense_sizes(d.O, d.E))
+        self.optimizer_step("model", SLOT_GN_MODEL, hp["model_learning_rate"])
+
+        # ======================= behaviour learning (dreamer.py:308-367) =======================
+        # imagination uses the post-update world model (packed by optimizer_step) and detached posteriors
+        ifeat, ent, act = self.imagine(feat, N, Hm, noise)
+        r_out, r_acts, r_layers = self.dense_forward("reward_model", "rew", "ir", ifeat, F, Mi, 1)
+        v_out, v_acts, v_layers = self.dense_forward("critic_target", "tgt", "iv", ifeat, F, Mi, 1)
+        returns = self.buf("returns", Mi)
+        cabi.check(lib.bd_lambda_return_forward(ptr(r_out), ptr(v_out), Hm, N, hp["discount"], hp["disclam"], ptr(returns), st))
+        cabi.check(lib.bd_sum(ptr(returns), Mi, sc, SLOT_RET, ws, st))
+        cabi.check(lib.bd_sum(ptr(ent), Mi, sc, SLOT_ENT, ws, st))
+        inv_mi = 1.0 / (Mi * W)
+        d_r, d_v = self.buf("d_ir_out", Mi), self.buf("d_iv_out", Mi)
+        cabi.check(lib.bd_lambda_return_backward(None, -inv_mi, Hm, N, hp["discount"], hp["disclam"], ptr(d_r), ptr(d_v), st))
+        difeat = self.buf("difeat", Mi, F)
+        self.mlp_backward(Mi, d_r, 1, r_layers, r_acts + [None], None, din0=difeat, ld0=F, w0=F)
+        self.mlp_backward(Mi, d_v, 1, v_layers, v_acts + [None], None, din0=difeat, ld0=F, w0=F, accumulate=True)
+        c = cabi.ImagineBwdArgs()
+        c.N, c.Hm, c.Be, c.S, c.A, c.Hd = N, Hm, d.Be, d.S, d.A, d.Hd
+        c.wt_embed_s, c.wt_embed_a = ptr(pk["embed_s.T"]), ptr(pk["embed_a.T"])
+        c.wt_ir, c.wt_iz, c.wt_in = ptr(pk["ir.T"]), ptr(pk["iz.T"]), ptr(pk["in.T"])
+        c.wt_hr, c.wt_hz, c.wt_hn = ptr(pk["hr.T"]), ptr(pk["hz.T"]), ptr(pk["hn.T"])
+        c.wt_p1, c.wt_p2m, c.wt_p2s = ptr(pk["p1.T"]), ptr(pk["p2m.T"]), ptr(pk["p2s.T"])
+        for l in range(1, DENSE_LAYERS):
+            c.wt_a[l - 1] = ptr(pk[f"a{l}.T"])
+        c.wt_a4m, c.wt_a4s = ptr(pk["a4m.T"]), ptr(pk["a4s.T"])
+        c.start_feat, c.feat, c.prior_std, c.action = ptr(feat), ptr(ifeat), ptr(self._buf["iprior_std"]), ptr(act)
+        c.eps_action, c.eps_prior = ptr(noise["action"]), ptr(noise["img_prior"])
+        sv_actor = self._buf["sv_actor"]
+        c.sv_actor, c.sv_act_stats = ptr(sv_actor), ptr(self._buf["sv_act_stats"])
+        c.sv_x, c.sv_gates, c.sv_p = ptr(self._buf["isv_x"]), ptr(self._buf["isv_gates"]), ptr(self._buf["isv_p"])
+        c.min_std = hp["min_std_dev"]
+        c.dfeat = ptr(difeat)
+        c.dentropy = -hp["entropy_weight"] * inv_mi if hp["entropy_weight"] != -1 else 0.0
+        d_apre, d_aout = self.buf("d_actor_pre", DENSE_LAYERS, Mi, d.Hd), self.buf("d_actor_out", Mi, 2 * d.A)
+        c.d_actor_pre, c.d_actor_out = ptr(d_apre), ptr(d_aout)
+        cabi.check(lib.bd_imagine_backward(C.byref(c), st))
+        Ga = lambda n: self.G("actor", n)
+        # layer 0 input = [h_t; s_t]: start features for t = 0, imagined features of step t-1 afterwards
+        self.wgrad(d_apre[0], d.Hd, feat, F, N, d.Hd, F, Ga("model.0.weight"), F, Ga("model.0.bias"))
+        if Hm > 1:
+            self.wgrad(d_apre[0][N:], d.Hd, ifeat, F, Mi - N, d.Hd, F, Ga("model.0.weight"), F, Ga("model.0.bias"),
+                       accumulate=True)
+        for l in range(1, DENSE_LAYERS):
+            self.wgrad(d_apre[l], d.Hd, sv_actor[l - 1], d.Hd, Mi, d.Hd, d.Hd, Ga(f"model.{2 * l}.weight"), d.Hd,
+                       Ga(f"model.{2 * l}.bias"))
+        self.wgrad(d_aout, 2 * d.A, sv_actor[DENSE_LAYERS - 1], d.Hd, Mi, 2 * d.A, d.Hd,
+                   Ga(f"model.{2 * DENSE_LAYERS}.weight"), d.Hd, Ga(f"model.{2 * DENSE_LAYERS}.bias"))
+        self.optimizer_step("actor", SLOT_GN_ACTOR, hp["actor_learning_rate"])
+
+        # ======================= critic (dreamer.py:370-391) =======================
+        c_out, c_acts, c_layers = self.dense_forward("critic", "cri", "ic", ifeat, F, Mi, 1)
+        d_c = self.buf("d_ic_out", Mi, 1)
+        cabi.check(lib.bd_normal_nll(ptr(c_out), 1, ptr(returns), 1, Mi, 1, inv_mi, ptr(d_c), 1, sc, SLOT_VAL, ws, st))
+        c_dpre = [self.buf(f"ic_dpre{l}", Mi, d.Hd) for l in range(DENSE_LAYERS)] + [d_c]
+        self.mlp_backward(Mi, d_c, 1, c_layers, c_acts + [None], c_dpre[:-1] + [None])
+        self._dense_wgrads("critic", Mi, c_dpre, ifeat, F, c_acts, dense_sizes(F, 1))
+        self.optimizer_step("critic", SLOT_GN_CRITIC, hp["value_learning_rate"])
+
+        self._counts = dict(N=N, Mi=Mi, S=d.S, sum_form=sum_form)
+        return self.logs() if sync_logs else {}
+
+    def logs(self) -> Dict[str, float]:
+        """One D2H copy of the scalar board -> the reference's log dict (src/dreamer.py:293-296,359-360,383).
+        Values are this rank's shard means (fp32 arithmetic as in the reference)."""
+        s = self.scalars.cpu().numpy().astype(np.float32)
+        hp, c = self.hp, self._counts
+        f32 = np.float32
+        N, Mi = f32(c["N"]), f32(c["Mi"])
+        obs, rew = s[SLOT_OBS] / N, s[SLOT_REW] / N
+        if c["sum_form"]:
+            kl = s[SLOT_KL] / N
+        else:
+            mean = s[SLOT_KL] / f32(c["N"] * c["S"] * self.world_size)
+            x = np.maximum(mean, f32(hp["free_nats"]))
+            kl = f32(hp["kl_balance"]) * x + f32(1 - hp["kl_balance"]) * x
+        ew = f32(hp["entropy_weight"]) if hp["entropy_weight"] != -1 else f32(0)
+        return {
+            "observation_loss": float(obs), "reward_loss": float(rew), "kl_loss": float(kl),
+            "model_loss": float(obs + rew + kl * f32(hp["kl_loss_weight"])),
+            "actor_loss": float(-(s[SLOT_RET] + ew * s[SLOT_ENT]) / Mi),
+            "policy_entropy": float(s[SLOT_ENT] / Mi),
+            "value_loss": float(s[SLOT_VAL] / Mi),
+            "grad_norm_model": float(math.sqrt(s[SLOT_GN_MODEL])), "grad_norm_actor": float(math.sqrt(s[SLOT_GN_ACTOR])),
+            "grad_norm_critic": float(math.sqrt(s[SLOT_GN_CRITIC])),
+        }

@@ -1,0 +1,279 @@
+/*
+ * bigdreamer_hip.h -- C ABI of the MI355X-native Dreamer world-model training step.
+ *
+ * The reference (jgsimard/big-dreamer) has no FFI / plugin interface: its hot path is a chain of
+ * ATen ops issued from Python.  This library is what a binding for that path
+ * binds instead; each entry point names the reference code it replaces.  The Python host in
+ * big_dreamer_amd/ (ctypes) mirrors the reference's own call surface on top of it
+ * (TransitionModel.forward, Dreamer.imagine_ahead, lambda_return, Dreamer.train_step ...).
+ *
+ * Conventions
+ *   - plain C, no torch types: raw device pointers (fp32 unless said otherwise), explicit sizes,
+ *     hipStream_t passed as void*;
+ *   - nothing allocates, frees or synchronises: every buffer (inputs, outputs, saved activations,
+ *     workspaces) is caller-owned device memory, every launch is asynchronous on `stream`;
+ *   - return value 0 = launched, negative = rejected (bd_last_error() has the text); never throws;
+ *   - tensors are contiguous row-major "rows x features" with an explicit leading dimension where one
+ *     is given; time-major (time, batch, feature) arrays are passed flattened to rows = time*batch;
+ *   - re-entrant per device: one host thread per GPU (one process per rank).
+ *
+ * Weight layout.  Kernels read weights in a packed MFMA-fragment layout produced by
+ * bd_pack_weights() from the PyTorch (out, in) row-major tensors: for W[N][K],
+ *   packed[nb][kb][lane][i] = W[nb*16 + (lane&15)][kb*16 + 4*(lane>>4) + i]   (zero padded),
+ * i.e. one coalesced 1 KiB read per 16x16 block feeds four v_mfma_f32_16x16x4_f32.
+ */
+#ifndef BIGDREAMER_HIP_H
+#define BIGDREAMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BD_MAX_LAYERS 6
+#define BD_ACT_NONE 0
+#define BD_ACT_ELU 1
+
+const char* bd_last_error(void);
+int bd_version(void);
+
+/* ---- weight packing ------------------------------------------------------------------------- */
+typedef struct {
+    const float* src; /* PyTorch-layout matrix, element (n,k) at src[n*ld + k]                  */
+    float* dst;       /* packed destination, bd_packed_floats(N,K) floats (transposed: (K,N))    */
+    int ld;           /* leading dimension of src                                                 */
+    int N, K;         /* logical sub-block to pack (rows n < N, cols k < K of src)                */
+    int transpose;    /* 0: pack W (out=N,in=K); 1: pack W^T (out=K,in=N) for the dgrad kernels  */
+} bd_pack_desc;
+
+size_t bd_packed_floats(int N, int K);
+/* descs: DEVICE array of n descriptors. */
+int bd_pack_weights(const bd_pack_desc* descs, int n, void* stream);
+
+/* ---- dense chains: DenseModel / build_mlp (src/models.py:365-408, src/utils.py:368-404) ------ */
+typedef struct {
+    const float* w;    /* packed weights (out=N, in=K)                                            */
+    const float* bias; /* [N] or NULL                                                             */
+    int N, K;
+    int act;           /* BD_ACT_*: applied to this layer's output                                */
+    float* save;       /* optional [M x N] post-activation output kept for the backward, or NULL  */
+} bd_layer;
+
+typedef struct {
+    int M;                          /* rows                                                       */
+    const float* in0; int ld0, w0;  /* input = [in0 | in1] (torch.cat(..., dim=-1)); in1 optional  */
+    const float* in1; int ld1, w1;
+    int n_layers;
+    bd_layer layer[BD_MAX_LAYERS];
+    float* out; int ldo;            /* last layer's output [M x N_last]                            */
+} bd_mlp_fwd_args;
+int bd_mlp_forward(const bd_mlp_fwd_args* a, void* stream);
+
+typedef struct {
+    const float* wt;   /* packed W^T (out=K, in=N) -- unused for layer 0 unless din requested      */
+    const float* saved;/* this layer's saved post-activation output [M x N] (needed iff act!=NONE) */
+    int N, K;
+    int act;
+    float* dpre;       /* optional [M x N] gradient w.r.t. the pre-activation (for bd_wgrad)        */
+} bd_layer_bwd;
+
+typedef struct {
+    int M;
+    const float* dout; int lddo;    /* gradient w.r.t. the last layer's output [M x N_last]        */
+    float dout_scale;               /* multiplies dout on load (1.0f for none)                     */
+    int n_layers;
+    bd_layer_bwd layer[BD_MAX_LAYERS];
+    float* din0; int ld0, w0;       /* optional gradient w.r.t. the input, split like the forward   */
+    float* din1; int ld1, w1;
+    int accumulate;                 /* 1: din += , 0: din =                                         */
+} bd_mlp_bwd_args;
+int bd_mlp_backward(const bd_mlp_bwd_args* a, void* stream);
+
+/* dW[N x K] (+)= dpre^T[N x M] * act[M x K],  db[N] (+)= column sums of dpre (db may be NULL).
+ * Deterministic split-M (slabs in `ws`, then a fixed-order reduction); accumulate=1 adds to dW/db.
+ * (What autograd's AddmmBackward computes for every nn.Linear on the path.) */
+size_t bd_wgrad_ws_floats(int M, int N, int K);
+int bd_wgrad(const float* dpre, int ldp, const float* act, int lda, int M, int N, int K,
+             float* dW, int ldw, float* db, int accumulate, float* ws, void* stream);
+
+/* ---- RSSM observe scan: TransitionModel.forward with embeddings (src/models.py:191-299) ------
+ * One persistent launch walks all T steps; a workgroup owns 16 batch rows (rows are independent, so
+ * there is no inter-workgroup synchronisation).  The prior head (src/models.py:256) does not feed the
+ * recurrence when embeddings are given, so the host runs it batched over all T*B rows afterwards
+ * (bd_mlp_forward + bd_gauss_head_forward).  The embedding half of the posterior's first layer is
+ * hoisted out of the loop: pre_emb = embeddings @ W_q1[:, Be:]^T. */
+typedef struct {
+    int T, B, Be, S, A, Hd;
+    /* packed weights */
+    const float* w_embed_s; const float* w_embed_a; const float* b_embed; /* fc_embed_state_action.0[:, :S] / [:, S:] */
+    const float* w_ir; const float* w_iz; const float* w_in;   /* rnn.weight_ih rows r,z,n (Be,Be) */
+    const float* w_hr; const float* w_hz; const float* w_hn;   /* rnn.weight_hh rows r,z,n (Be,Be) */
+    const float* b_ih; const float* b_hh;                       /* [3*Be] each                      */
+    const float* w_q1h; const float* b_q1;         /* belief_posterior.model.0[:, :Be]: (Hd, Be)   */
+    const float* w_q2m; const float* w_q2s;        /* belief_posterior.model.2 rows [0,S) / [S,2S) */
+    const float* b_q2;                             /* [2*S]                                        */
+    /* inputs */
+    const float* init_belief;  /* [B x Be]                                                        */
+    const float* init_state;   /* [B x S]                                                         */
+    const float* actions;      /* [T x B x A]                                                     */
+    const float* nonterm;      /* [T x B] or NULL (nonterminals=None, src/models.py:247)          */
+    const float* pre_emb;      /* [T x B x Hd] hoisted embedding projection (no bias)              */
+    const float* eps_post;     /* [T x B x S] standard normal                                     */
+    float min_std;             /* 0.1                                                             */
+    /* outputs */
+    float* feat;      /* [T x B x (Be+S)]: [belief_{t+1} | posterior_state_{t+1}]                  */
+    float* post_mean; /* [T x B x S]                                                              */
+    float* post_std;  /* [T x B x S]                                                              */
+    /* saved for the backward (all NULL for inference) */
+    float* sv_s;      /* [T x B x S]  masked previous state (input of the embed layer)             */
+    float* sv_x;      /* [T x B x Be] embed output                                                 */
+    float* sv_gates;  /* [T x B x 4*Be]: r, z, n, (W_hn h + b_hn)                                  */
+    float* sv_q;      /* [T x B x Hd] posterior hidden (post-ELU)                                  */
+} bd_observe_fwd_args;
+int bd_observe_forward(const bd_observe_fwd_args* a, void* stream);
+
+typedef struct {
+    int T, B, Be, S, A, Hd;
+    /* transposed packed weights */
+    const float* wt_embed_s;                                 /* (S, Be)                            */
+    const float* wt_ir; const float* wt_iz; const float* wt_in;
+    const float* wt_hr; const float* wt_hz; const float* wt_hn;
+    const float* wt_q1h;                                     /* (Be, Hd)                           */
+    const float* wt_q2m; const float* wt_q2s;                /* (Hd, S) each                        */
+    /* forward inputs / saved */
+    const float* init_belief; const float* nonterm; const float* eps_post;
+    const float* feat; const float* post_std;
+    const float* sv_x; const float* sv_gates; const float* sv_q;
+    /* incoming gradients */
+    const float* dfeat;      /* [T x B x (Be+S)] from the obs/reward heads (+ prior head on the belief part) */
+    const float* dpost_mean; /* [T x B x S] from the KL term (or NULL)                              */
+    const float* dpost_std;  /* [T x B x S] (or NULL)                                               */
+    float min_std;
+    /* outputs: pre-activation gradients for bd_wgrad */
+    float* d_embed_pre;  /* [T x B x Be]                                                            */
+    float* d_gi;         /* [T x B x 3*Be] (r,z,n) gradient w.r.t. W_ih x + b_ih                     */
+    float* d_gh;         /* [T x B x 3*Be] gradient w.r.t. W_hh h + b_hh                             */
+    float* d_q1_pre;     /* [T x B x Hd]   (also the gradient of pre_emb)                            */
+    float* d_q2_out;     /* [T x B x 2*S]                                                           */
+} bd_observe_bwd_args;
+int bd_observe_backward(const bd_observe_bwd_args* a, void* stream);
+
+/* GaussianBeliefModel tail (src/models.py:70-73): out[M x 2S] -> mean, std=softplus(raw)+min_std,
+ * state = mean + std*eps.  Used for the batched prior of the observe scan. */
+int bd_gauss_head_forward(const float* out, const float* eps, int M, int S, float min_std,
+                          float* mean, float* std, float* state, void* stream);
+/* d out = [dmean + dstate, (dstd + dstate*eps) * sigmoid(raw)];  dstate/dmean/dstd may be NULL */
+int bd_gauss_head_backward(const float* out, const float* eps, const float* dstate, const float* dmean,
+                           const float* dstd, int M, int S, float* dout, void* stream);
+
+/* ---- imagination rollout: Dreamer.imagine_ahead + get_action (src/dreamer.py:179-237,429-444),
+ *      ActorModel (src/models.py:506-517), SampleDist.entropy / TanhBijector (src/models.py:630-733).
+ * One persistent launch walks all Hm = planning_horizon-1 steps; a workgroup owns 16 trajectories. */
+typedef struct {
+    int N, Hm, Be, S, A, Hd, n_samples;
+    /* frozen world model (packed) */
+    const float* w_embed_s; const float* w_embed_a; const float* b_embed;
+    const float* w_ir; const float* w_iz; const float* w_in;
+    const float* w_hr; const float* w_hz; const float* w_hn;
+    const float* b_ih; const float* b_hh;
+    const float* w_p1; const float* b_p1;          /* belief_prior.model.0 (Hd, Be)                 */
+    const float* w_p2m; const float* w_p2s; const float* b_p2;
+    /* actor (packed): layer 0 split in belief / state columns, 3 more hidden layers, output layer split
+       in mean rows / std rows (model.8: (2A, Hd)) */
+    const float* w_a0h; const float* w_a0s; const float* w_a[3]; const float* b_a[4];
+    const float* w_a4m; const float* w_a4s; const float* b_a4;
+    /* inputs */
+    const float* start_feat;   /* [N x (Be+S)] detached posterior features                          */
+    const float* eps_action;   /* [Hm x N x A]                                                      */
+    const float* eps_entropy;  /* [Hm x n_samples x N x A]                                          */
+    const float* eps_prior;    /* [Hm x N x S]                                                      */
+    float min_std, act_raw_init_std, act_min_std, act_mean_scale;
+    /* outputs */
+    float* feat;          /* [Hm x N x (Be+S)] imagined [belief | prior_state]                      */
+    float* prior_mean;    /* [Hm x N x S] (may be NULL)                                             */
+    float* prior_std;     /* [Hm x N x S]                                                           */
+    float* entropy;       /* [Hm x N]                                                               */
+    float* action;        /* [Hm x N x A] tanh-squashed sample                                      */
+    /* saved for the backward (all NULL for inference) */
+    float* sv_actor;      /* [4][Hm x N x Hd] actor hidden activations                              */
+    float* sv_act_stats;  /* [Hm x N x 4A]: tanh(m/scale), sigmoid(raw+init), d ent/d mean, d ent/d std */
+    float* sv_x;          /* [Hm x N x Be]                                                          */
+    float* sv_gates;      /* [Hm x N x 4*Be]                                                        */
+    float* sv_p;          /* [Hm x N x Hd]                                                          */
+} bd_imagine_fwd_args;
+int bd_imagine_forward(const bd_imagine_fwd_args* a, void* stream);
+
+typedef struct {
+    int N, Hm, Be, S, A, Hd;
+    const float* wt_embed_s; const float* wt_embed_a;        /* (S, Be), (A, Be)                    */
+    const float* wt_ir; const float* wt_iz; const float* wt_in;
+    const float* wt_hr; const float* wt_hz; const float* wt_hn;
+    const float* wt_p1; const float* wt_p2m; const float* wt_p2s;
+    const float* wt_a[3];                 /* transposes of actor layers 1..3 (layer 0: input detached) */
+    const float* wt_a4m; const float* wt_a4s;                /* (Hd, A) each                        */
+    /* forward tensors */
+    const float* start_feat; const float* feat; const float* prior_std; const float* action;
+    const float* eps_action; const float* eps_prior;
+    const float* sv_actor; const float* sv_act_stats; const float* sv_x; const float* sv_gates;
+    const float* sv_p;
+    float min_std;
+    /* incoming gradients */
+    const float* dfeat;     /* [Hm x N x (Be+S)] from reward / value heads                           */
+    float dentropy;         /* d loss / d entropy[t][n] (constant: -entropy_weight/(Hm*N))           */
+    /* outputs for bd_wgrad */
+    float* d_actor_pre;     /* [4][Hm x N x Hd]                                                     */
+    float* d_actor_out;     /* [Hm x N x 2A]                                                        */
+} bd_imagine_bwd_args;
+int bd_imagine_backward(const bd_imagine_bwd_args* a, void* stream);
+
+/* ---- lambda-return (src/dreamer.py:447-471); bootstrap = value[Hm-1] as at dreamer.py:332 ----- */
+int bd_lambda_return_forward(const float* reward, const float* value, int Hm, int N, float discount,
+                             float lambda_, float* returns, void* stream);
+/* gradient of the scan: d returns = dreturns[Hm x N] if non-NULL else the constant dret_const.
+ * Writes dreward and dvalue (dvalue[0] = 0: value[0] is never used; the bootstrap duplicate of
+ * value[Hm-1] is folded into dvalue[Hm-1]). */
+int bd_lambda_return_backward(const float* dreturns, float dret_const, int Hm, int N, float discount,
+                              float lambda_, float* dreward, float* dvalue, void* stream);
+
+/* ---- losses (src/planet.py:252-284, src/dreamer.py:110-146,342-383) ---------------------------
+ * Reductions write RAW SUMS into a small device "scalar board" (float array); the host turns them
+ * into the logged means after one D2H copy per step, and multi-GPU runs all-reduce the board's KL slot
+ * before the free-nats clamp.  Each reduction is two launches: per-workgroup fp64 partials in `ws`
+ * (bd_reduce_ws_floats() floats), then a fixed-order final sum (deterministic, no float atomics). */
+/* scalars[slot] = sum over all elements of 0.5 (t-p)^2 + 0.5 ln 2pi;  dpred = (p-t) * grad_scale
+ * (-Independent(Normal(pred,1)).log_prob(target); dpred may be NULL) */
+int bd_normal_nll(const float* pred, int ldp, const float* target, int ldt, int rows, int D,
+                  float grad_scale, float* dpred, int ldd, float* scalars, int slot, float* ws, void* stream);
+/* balanced form (sum_form=0): scalars[slot] = sum of elementwise KL(N(qm,qs) || N(pm,ps));
+ * summed form  (sum_form=1, kl_balance == -1): scalars[slot] = sum_rows max(sum_S KL, free_nats) */
+int bd_kl_forward(const float* qm, const float* qs, const float* pm, const float* ps, int rows, int S,
+                  float free_nats, int sum_form, float* scalars, int slot, float* ws, void* stream);
+/* Gradients of weight * kl_loss.  Balanced: the clamp decision uses mean = scalars[slot] * inv_count
+ * (inv_count = 1 / global element count, after any all-reduce of the slot). */
+int bd_kl_backward(const float* qm, const float* qs, const float* pm, const float* ps, int rows, int S,
+                   float free_nats, float kl_balance, float weight, float inv_count, const float* scalars,
+                   int slot, float* dqm, float* dqs, float* dpm, float* dps, void* stream);
+/* scalars[slot] = sum(x) / sum(x^2) */
+int bd_sum(const float* x, size_t n, float* scalars, int slot, float* ws, void* stream);
+int bd_sumsq(const float* x, size_t n, float* scalars, int slot, float* ws, void* stream);
+
+/* ---- clip_grad_norm_ + Adam (src/dreamer.py:299-302,362-367,386-391; torch.optim.Adam with
+ *      weight_decay = L2-in-gradient).  total_norm = sqrt(scalars[sqnorm_slot]); the gradient buffer
+ *      is left clipped, as the reference leaves .grad. */
+int bd_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int step, float max_norm, const float* scalars,
+                 int sqnorm_slot, void* stream);
+/* polyak_update (src/utils.py:56-78): target = src*weight + target*(1-weight) */
+int bd_polyak(float* target, const float* src, size_t n, float weight, void* stream);
+
+/* ---- replay gather: ExperienceReplay._retrieve_batch (src/memory.py:70-85) --------------------- */
+int bd_replay_gather(const float* src, const int64_t* idx, int n_idx, int width, float* dst, void* stream);
+
+size_t bd_reduce_ws_floats(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIGDREAMER_HIP_H */
