@@ -98,7 +98,7 @@ _SIGS = {
     "bd_mlp_forward": (I32, [C.POINTER(MlpFwdArgs), P]),
     "bd_mlp_backward": (I32, [C.POINTER(MlpBwdArgs), P]),
     "bd_wgrad_ws_floats": (C.c_size_t, [I32, I32, I32]),
-    "bd_wgrad": (I32, [P, I32, P, I32, I32, I32, I32, P, I32, P, I32, P, P]),
+    "bd_wgrad": (I32, [P, I32, P, I32, I32, I32, I32, P, I32, P, I32, P, C.c_size_t, P]),
     "bd_observe_forward": (I32, [C.POINTER(ObserveFwdArgs), P]),
     "bd_observe_backward": (I32, [C.POINTER(ObserveBwdArgs), P]),
     "bd_gauss_head_forward": (I32, [P, P, I32, I32, F32, P, P, P, P]),

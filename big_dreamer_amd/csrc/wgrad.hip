@@ -92,19 +92,24 @@ static void wgrad_plan(int M, int N, int K, int has_bias, int* splits, int* rows
 extern "C" {
 
 size_t bd_wgrad_ws_floats(int M, int N, int K) {
-    int s, rp;
-    bd::wgrad_plan(M, N, K, 1, &s, &rp);
-    return (size_t)s * N * (K + 1);
+    // the split count depends on whether the bias column is appended: cover both forms
+    int s0, s1, rp;
+    bd::wgrad_plan(M, N, K, 0, &s0, &rp);
+    bd::wgrad_plan(M, N, K, 1, &s1, &rp);
+    const size_t a = (size_t)s0 * N * K, b = (size_t)s1 * N * (K + 1);
+    return a > b ? a : b;
 }
 
 int bd_wgrad(const float* dpre, int ldp, const float* act, int lda, int M, int N, int K, float* dW, int ldw,
-             float* db, int accumulate, float* ws, void* stream) {
+             float* db, int accumulate, float* ws, size_t ws_floats, void* stream) {
     using namespace bd;
     BD_REQUIRE(dpre && act && dW && ws && M > 0 && N > 0 && K > 0, "bd_wgrad: bad arguments");
     BD_REQUIRE(ldp >= N && lda >= K && ldw >= K, "bd_wgrad: leading dimension too small");
     const int hb = db != nullptr;
     int splits, rows_per;
     wgrad_plan(M, N, K, hb, &splits, &rows_per);
+    BD_REQUIRE((size_t)splits * N * (K + hb) <= ws_floats, "bd_wgrad: workspace too small (%zu floats, need %zu)",
+               ws_floats, (size_t)splits * N * (K + hb));
     hipLaunchKernelGGL(wgrad_kernel, dim3(cdiv(N, kWT), cdiv(K + hb, kWT), splits), dim3(kThreads), 0,
                        (hipStream_t)stream, dpre, ldp, act, lda, M, N, K, hb, rows_per, ws);
     BD_CHECK_LAUNCH("bd_wgrad");

@@ -91,9 +91,41 @@ class DreamerEngine:
         self.red_ws = torch.zeros(int(lib.bd_reduce_ws_floats()), dtype=torch.float32, device=self.dev)
         self._wgrad_ws = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self._buf: Dict[str, torch.Tensor] = {}
+        self._timers_on = False
+        self._timer_events: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
         self._build_pack_tables()
         for g in ("model", "actor", "critic", "critic_target"):
             self.pack(g)
+
+    # ------------------------------------------------------------------------------------------ timing
+    class _Span:
+        """HIP-event pair recorded on the launch stream around a group of kernel launches."""
+
+        def __init__(self, eng, name):
+            self.eng, self.name = eng, name
+
+        def __enter__(self):
+            if self.eng._timers_on:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e1 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+
+        def __exit__(self, *exc):
+            if self.eng._timers_on:
+                self.e1.record()
+                self.eng._timer_events.setdefault(self.name, []).append((self.e0, self.e1))
+
+    def span(self, name: str) -> "DreamerEngine._Span":
+        return DreamerEngine._Span(self, name)
+
+    def enable_timers(self, on: bool) -> None:
+        self._timers_on = on
+        if on:
+            self._timer_events = {}
+
+    def timer_summary(self) -> Dict[str, Tuple[float, int]]:
+        """{span: (average ms, count)}; call after a device synchronise."""
+        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in self._timer_events.items()}
 
     # ------------------------------------------------------------------------------------------ params
     def W(self, mod: str, name: str) -> torch.Tensor:
@@ -220,7 +252,7 @@ class DreamerEngine:
         if self._wgrad_ws.numel() < need:
             self._wgrad_ws = torch.zeros(need, dtype=torch.float32, device=self.dev)
         cabi.check(lib.bd_wgrad(ptr(dpre), ldp, ptr(act), lda, M, N, K, ptr(dW), ldw, ptr(db), int(accumulate),
-                                ptr(self._wgrad_ws), cabi.stream()))
+                                ptr(self._wgrad_ws), self._wgrad_ws.numel(), cabi.stream()))
 
     def _dense_wgrads(self, mod: str, M: int, dpres, inp, ld_in, saves, sizes) -> None:
         """Weight/bias gradients of a DenseModel from its pre-activation gradients."""
@@ -284,7 +316,8 @@ class DreamerEngine:
         if save:
             a.sv_s, a.sv_x = ptr(self.buf("sv_s", M, d.S)), ptr(self.buf("sv_x", M, d.Be))
             a.sv_gates, a.sv_q = ptr(self.buf("sv_gates", M, 4 * d.Be)), ptr(self.buf("sv_q", M, d.Hd))
-        cabi.check(lib.bd_observe_forward(C.byref(a), cabi.stream()))
+        with self.span("observe_fwd"):
+            cabi.check(lib.bd_observe_forward(C.byref(a), cabi.stream()))
         return feat, qm, qs
 
     def prior_head(self, feat, M: int, eps):
@@ -341,7 +374,8 @@ class DreamerEngine:
             a.sv_act_stats = ptr(self.buf("sv_act_stats", Mi, 4 * d.A))
             a.sv_x, a.sv_gates = ptr(self.buf("isv_x", Mi, d.Be)), ptr(self.buf("isv_gates", Mi, 4 * d.Be))
             a.sv_p = ptr(self.buf("isv_p", Mi, d.Hd))
-        cabi.check(lib.bd_imagine_forward(C.byref(a), cabi.stream()))
+        with self.span("imagine_fwd"):
+            cabi.check(lib.bd_imagine_forward(C.byref(a), cabi.stream()))
         return ifeat, ent, act
 
     # ------------------------------------------------------------------------------------------ train step
@@ -374,13 +408,15 @@ class DreamerEngine:
 
         # ======================= dynamics learning (dreamer.py:263-302) =======================
         obs_t = obs[1:].reshape(N, d.O)                     # targets and encoder input
-        emb, pre_emb = self.encode(obs_t, N)
+        with self.span("encoder_fwd"):
+            emb, pre_emb = self.encode(obs_t, N)
         init_belief = self.buf("init_belief", B, d.Be).zero_()
         init_state = self.buf("init_state", B, d.S).zero_()
         feat, qm, qs = self.observe(actions[:-1], nonterm[:-1], pre_emb, noise["obs_post"], init_belief, init_state, T, B)
-        _, pm, ps = self.prior_head(feat, N, noise["obs_prior"])
-        om_out, om_acts, om_layers = self.dense_forward("observation_model", "obs", "om", feat, F, N, d.O)
-        rw_out, rw_acts, rw_layers = self.dense_forward("reward_model", "rew", "rw", feat, F, N, 1)
+        with self.span("wm_heads_fwd"):
+            _, pm, ps = self.prior_head(feat, N, noise["obs_prior"])
+            om_out, om_acts, om_layers = self.dense_forward("observation_model", "obs", "om", feat, F, N, d.O)
+            rw_out, rw_acts, rw_layers = self.dense_forward("reward_model", "rew", "rw", feat, F, N, 1)
 
         inv_rows = 1.0 / (N * W)
         d_om, d_rw = self.buf("d_om_out", N, d.O), self.buf("d_rw_out", N, 1)
@@ -429,7 +465,8 @@ class DreamerEngine:
         d_e, d_gi, d_gh = self.buf("d_embed_pre", N, d.Be), self.buf("d_gi", N, 3 * d.Be), self.buf("d_gh", N, 3 * d.Be)
         d_q1, d_q2 = self.buf("d_q1_pre", N, d.Hd), self.buf("d_q2_out", N, 2 * d.S)
         b.d_embed_pre, b.d_gi, b.d_gh, b.d_q1_pre, b.d_q2_out = ptr(d_e), ptr(d_gi), ptr(d_gh), ptr(d_q1), ptr(d_q2)
-        cabi.check(lib.bd_observe_backward(C.byref(b), st))
+        with self.span("observe_bwd"):
+            cabi.check(lib.bd_observe_backward(C.byref(b), st))
         # encoder (+ hoisted projection as its last layer)
         enc_layers = self._dense_spec("encoder", "enc", d.O, d.E) + [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)]
         enc_acts = [self._buf[f"enc_act{l}"] for l in range(DENSE_LAYERS)]
@@ -458,13 +495,15 @@ class DreamerEngine:
         self._dense_wgrads("observation_model", N, om_dpre, feat, F, om_acts, dense_sizes(F, d.O))
         self._dense_wgrads("reward_model", N, rw_dpre, feat, F, rw_acts, dense_sizes(F, 1))
         self._dense_wgrads("encoder", N, enc_dpre, obs_t, d.O, enc_acts, dense_sizes(d.O, d.E))
-        self.optimizer_step("model", SLOT_GN_MODEL, hp["model_learning_rate"])
+        with self.span("opt_model"):
+            self.optimizer_step("model", SLOT_GN_MODEL, hp["model_learning_rate"])
 
         # ======================= behaviour learning (dreamer.py:308-367) =======================
         # imagination uses the post-update world model (packed by optimizer_step) and detached posteriors
         ifeat, ent, act = self.imagine(feat, N, Hm, noise)
-        r_out, r_acts, r_layers = self.dense_forward("reward_model", "rew", "ir", ifeat, F, Mi, 1)
-        v_out, v_acts, v_layers = self.dense_forward("critic_target", "tgt", "iv", ifeat, F, Mi, 1)
+        with self.span("img_heads_fwd"):
+            r_out, r_acts, r_layers = self.dense_forward("reward_model", "rew", "ir", ifeat, F, Mi, 1)
+            v_out, v_acts, v_layers = self.dense_forward("critic_target", "tgt", "iv", ifeat, F, Mi, 1)
         returns = self.buf("returns", Mi)
         cabi.check(lib.bd_lambda_return_forward(ptr(r_out), ptr(v_out), Hm, N, hp["discount"], hp["disclam"], ptr(returns), st))
         cabi.check(lib.bd_sum(ptr(returns), Mi, sc, SLOT_RET, ws, st))
@@ -473,8 +512,9 @@ class DreamerEngine:
         d_r, d_v = self.buf("d_ir_out", Mi), self.buf("d_iv_out", Mi)
         cabi.check(lib.bd_lambda_return_backward(None, -inv_mi, Hm, N, hp["discount"], hp["disclam"], ptr(d_r), ptr(d_v), st))
         difeat = self.buf("difeat", Mi, F)
-        self.mlp_backward(Mi, d_r, 1, r_layers, r_acts + [None], None, din0=difeat, ld0=F, w0=F)
-        self.mlp_backward(Mi, d_v, 1, v_layers, v_acts + [None], None, din0=difeat, ld0=F, w0=F, accumulate=True)
+        with self.span("img_heads_bwd"):
+            self.mlp_backward(Mi, d_r, 1, r_layers, r_acts + [None], None, din0=difeat, ld0=F, w0=F)
+            self.mlp_backward(Mi, d_v, 1, v_layers, v_acts + [None], None, din0=difeat, ld0=F, w0=F, accumulate=True)
         c = cabi.ImagineBwdArgs()
         c.N, c.Hm, c.Be, c.S, c.A, c.Hd = N, Hm, d.Be, d.S, d.A, d.Hd
         c.wt_embed_s, c.wt_embed_a = ptr(pk["embed_s.T"]), ptr(pk["embed_a.T"])
@@ -494,7 +534,8 @@ class DreamerEngine:
         c.dentropy = -hp["entropy_weight"] * inv_mi if hp["entropy_weight"] != -1 else 0.0
         d_apre, d_aout = self.buf("d_actor_pre", DENSE_LAYERS, Mi, d.Hd), self.buf("d_actor_out", Mi, 2 * d.A)
         c.d_actor_pre, c.d_actor_out = ptr(d_apre), ptr(d_aout)
-        cabi.check(lib.bd_imagine_backward(C.byref(c), st))
+        with self.span("imagine_bwd"):
+            cabi.check(lib.bd_imagine_backward(C.byref(c), st))
         Ga = lambda n: self.G("actor", n)
         # layer 0 input = [h_t; s_t]: start features for t = 0, imagined features of step t-1 afterwards
         self.wgrad(d_apre[0], d.Hd, feat, F, N, d.Hd, F, Ga("model.0.weight"), F, Ga("model.0.bias"))
@@ -506,7 +547,8 @@ class DreamerEngine:
                        Ga(f"model.{2 * l}.bias"))
         self.wgrad(d_aout, 2 * d.A, sv_actor[DENSE_LAYERS - 1], d.Hd, Mi, 2 * d.A, d.Hd,
                    Ga(f"model.{2 * DENSE_LAYERS}.weight"), d.Hd, Ga(f"model.{2 * DENSE_LAYERS}.bias"))
-        self.optimizer_step("actor", SLOT_GN_ACTOR, hp["actor_learning_rate"])
+        with self.span("opt_actor"):
+            self.optimizer_step("actor", SLOT_GN_ACTOR, hp["actor_learning_rate"])
 
         # ======================= critic (dreamer.py:370-391) =======================
         c_out, c_acts, c_layers = self.dense_forward("critic", "cri", "ic", ifeat, F, Mi, 1)
@@ -515,7 +557,8 @@ class DreamerEngine:
         c_dpre = [self.buf(f"ic_dpre{l}", Mi, d.Hd) for l in range(DENSE_LAYERS)] + [d_c]
         self.mlp_backward(Mi, d_c, 1, c_layers, c_acts + [None], c_dpre[:-1] + [None])
         self._dense_wgrads("critic", Mi, c_dpre, ifeat, F, c_acts, dense_sizes(F, 1))
-        self.optimizer_step("critic", SLOT_GN_CRITIC, hp["value_learning_rate"])
+        with self.span("opt_critic"):
+            self.optimizer_step("critic", SLOT_GN_CRITIC, hp["value_learning_rate"])
 
         self._counts = dict(N=N, Mi=Mi, S=d.S, sum_form=sum_form)
         return self.logs() if sync_logs else {}

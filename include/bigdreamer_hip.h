@@ -92,11 +92,12 @@ typedef struct {
 int bd_mlp_backward(const bd_mlp_bwd_args* a, void* stream);
 
 /* dW[N x K] (+)= dpre^T[N x M] * act[M x K],  db[N] (+)= column sums of dpre (db may be NULL).
- * Deterministic split-M (slabs in `ws`, then a fixed-order reduction); accumulate=1 adds to dW/db.
+ * Deterministic split-M (slabs in `ws`, then a fixed-order reduction); accumulate=1 adds to dW/db;
+ * ws must hold bd_wgrad_ws_floats(M,N,K) floats (its capacity ws_floats is checked).
  * (What autograd's AddmmBackward computes for every nn.Linear on the path.) */
 size_t bd_wgrad_ws_floats(int M, int N, int K);
 int bd_wgrad(const float* dpre, int ldp, const float* act, int lda, int M, int N, int K,
-             float* dW, int ldw, float* db, int accumulate, float* ws, void* stream);
+             float* dW, int ldw, float* db, int accumulate, float* ws, size_t ws_floats, void* stream);
 
 /* ---- RSSM observe scan: TransitionModel.forward with embeddings (src/models.py:191-299) ------
  * One persistent launch walks all T steps; a workgroup owns 16 batch rows (rows are independent, so

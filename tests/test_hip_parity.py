@@ -137,3 +137,23 @@ def test_train_steps_vs_oracle_and_golden(name):
                     compare_tensor(g, f"step{step}.param.{mod}.{k}", got, full, atol=2e-5, rtol=1e-5)
     finally:
         print("\n".join(rep[-400:]))
+
+
+def test_replay_sample_on_device_matches_reference_golden():
+    """R0 through bd_replay_gather: same draws -> the reference's batches (bit exact, pure copies)."""
+    from big_dreamer_amd.memory import ExperienceReplay
+    g = load_golden("replay")
+    d = synth.TINY
+    rep = synth.make_replay(d, rows=64, seed=3)
+    for case, (idx, full) in {"partial": (40, False), "wrapped": (17, True)}.items():
+        buf = ExperienceReplay(64, d.A, 5, False, d.O, "cuda")
+        for k, v in rep.items():
+            getattr(buf, k)[:] = v
+        buf.idx, buf.full = idx, full
+        np.random.seed(11)
+        o, a, r, n = buf.sample(6, 7)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(o.cpu().numpy(), g[f"{case}.observations"])
+        np.testing.assert_array_equal(a.cpu().numpy(), g[f"{case}.actions"])
+        np.testing.assert_array_equal(r.cpu().numpy(), g[f"{case}.rewards"])
+        np.testing.assert_array_equal(n.cpu().numpy(), g[f"{case}.nonterminals"])
