@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbigdreamer_hip.so")
+# BD_LIB selects an alternative build of the same library (kernel tuning experiments only)
+LIB_PATH = os.environ.get("BD_LIB") or os.path.join(_HERE, "libbigdreamer_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -20,7 +20,11 @@ namespace bd {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-constexpr int kWaves = 4;          // waves per workgroup (one per SIMD)
+#ifndef BD_WAVES
+#define BD_WAVES 4
+#endif
+constexpr int kWaves = BD_WAVES;   // waves per workgroup (BD_WAVES/4 per SIMD)
+constexpr int kNI = 2;             // (legacy template argument; the block loop keeps up to two column blocks in flight)
 constexpr int kThreads = kWaves * 64;
 constexpr int kFragFloats = 256;   // floats per [16 rows x 16 k] fragment block
 
@@ -29,6 +33,17 @@ __device__ __forceinline__ floatx4 mfma16(float a, float b, floatx4 c) {
 }
 
 __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc emit s_waitcnt vmcnt(0), and
+// on CDNA4 vmcnt counts global STORES too: every phase of a persistent kernel would wait for its
+// saved-activation stores to be acknowledged by L2.  The tile kernels hand data between phases through LDS
+// only (global buffers are write-only or read-only within a launch), so: drain this wave's LDS operations,
+// then a bare s_barrier; stores stay in flight.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 // float index of element (row, k) of a [16 x 16*Kb] fragment tile
 __device__ __forceinline__ int frag_idx(int row, int k) {
@@ -91,130 +106,166 @@ __device__ __forceinline__ void load_tile_concat(float* __restrict__ X, int Kb, 
     }
 }
 
-// ---- the core: [16*RT x K] (LDS, fragment order) times packed W^T -> accumulators ------------------
-// Each wave owns output column blocks nb = wave, wave+4, ...; NI of them are kept in flight to give
-// the MFMA pipe independent accumulation chains (16x16x4 f32: 32-cycle issue, 40-cycle dependent).
-// epi(rt, nb, acc): lane holds out[row = 4*(lane>>4) + r][col = nb*16 + (lane&15)], r = 0..3.
-template <int RT, int NI, class Epi>
-__device__ __forceinline__ void tile_linear(const float* __restrict__ X, int Kb, const float* __restrict__ Wp,
-                                            const float* __restrict__ bias, int N, Epi&& epi) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int Nb = (N + 15) >> 4;
-    const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(X) + lane;
-    const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(Wp) + lane;
-    for (int nb0 = wave; nb0 < Nb; nb0 += kWaves * NI) {
-        floatx4 acc[NI][RT];
-        const floatx4* wp[NI];
+// ---- software-pipelined block loop ------------------------------------------------------------------
+// load(kb) returns the fragments of block kb (global weight float4s + LDS activation float4s); mma(frag)
+// consumes them.  Two register sets of D blocks each: while the MFMAs consume set A, the loads of the next D
+// blocks land in set B (and vice versa), so L2 latency overlaps MFMA issue.  The sets are distinct variables
+// on purpose: with a single ring hipcc coalesces "cur = ring[i]; ring[i] = load" into one register range and
+// must drain (vmcnt(0)) before it can refill.  The (< D) tail blocks are fetched first and consumed last.
+// All indices are compile-time constants (fully unrolled) -> everything is in VGPRs and hipcc emits counted
+// s_waitcnt vmcnt(N).  (Measured on MI355X: a deeper flat ring pinned with sched_barrier was slower.)
+template <int D, class LoadF, class MmaF>
+__device__ __forceinline__ void pipelined_k(int Kb, LoadF&& load, MmaF&& mma) {
+    using Frag = decltype(load(0));
+    const int G = Kb / D, nt = Kb - G * D;   // full groups, tail blocks (< D)
+    Frag A[D], B[D];
+    Frag T[D > 1 ? D - 1 : 1];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int nb = nb0 + i * kWaves;
-            const int nbc = nb < Nb ? nb : Nb - 1;          // clamp: stay in bounds, result discarded
-            wp[i] = W4 + (size_t)nbc * Kb * 64;
-            const int col = nb * 16 + (lane & 15);
-            const float b = (bias != nullptr && col < N) ? bias[col] : 0.f;
+    for (int i = 0; i < D - 1; ++i)
+        if (i < nt) T[i] = load(G * D + i);
+    if (G > 0) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[i][rt] = floatx4{b, b, b, b};
+        for (int i = 0; i < D; ++i) A[i] = load(i);
+        int g = 1;
+        for (; g + 1 < G; g += 2) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) B[i] = load(g * D + i);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < D; ++i) mma(A[i]);
+#pragma unroll
+            for (int i = 0; i < D; ++i) A[i] = load((g + 1) * D + i);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < D; ++i) mma(B[i]);
         }
-        for (int kb = 0; kb < Kb; ++kb) {
-            floatx4 b4[NI], a4[RT];
+        if (g < G) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) b4[i] = wp[i][kb * 64];
+            for (int i = 0; i < D; ++i) B[i] = load(g * D + i);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) a4[rt] = X4[(rt * Kb + kb) * 64];
+            for (int i = 0; i < D; ++i) mma(A[i]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < D; ++i) mma(B[i]);
+        } else {
 #pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) acc[i][rt] = mfma16(a4[rt][j], b4[i][j], acc[i][rt]);
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int nb = nb0 + i * kWaves;
-            if (nb < Nb) {
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) epi(rt, nb, acc[i][rt]);
-            }
-        }
-    }
-}
-
-// Same contraction accumulated on top of caller-provided accumulators for ONE column block; used where
-// several weight matrices feed the same output element (GRU gates, split mean/std heads).
-template <int RT>
-__device__ __forceinline__ void tile_accum(const float* __restrict__ X, int Kb, const float* __restrict__ Wp,
-                                           int nb, floatx4 (&acc)[RT]) {
-    const int lane = threadIdx.x & 63;
-    const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(X) + lane;
-    const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(Wp) + lane + (size_t)nb * Kb * 64;
-    for (int kb = 0; kb < Kb; ++kb) {
-        const floatx4 b4 = W4[kb * 64];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const floatx4 a4 = X4[(rt * Kb + kb) * 64];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[rt] = mfma16(a4[j], b4[j], acc[rt]);
+            for (int i = 0; i < D; ++i) mma(A[i]);
         }
     }
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i)
+        if (i < nt) mma(T[i]);
 }
 
-// ---- multi-segment contraction ------------------------------------------------------------------------
-// out = sum_s X_s * W_s^T + bias: the concatenated inputs of the reference (torch.cat([belief, state]),
-// cat(state, action)) are kept as separate LDS fragments with separately packed weight column blocks.
+// ---- the core contraction: out[16*RT x N] = sum_s X_s[16*RT x K_s] * W_s^T + bias -----------------------
+// The reference's concatenated inputs (torch.cat([belief, state]), cat(state, action)) are kept as separate
+// LDS fragment tiles ("segments") with separately packed weight column blocks.
 struct Seg {
-    const float* X;   // LDS fragment tile [Kb][64][4]
+    const float* X;   // LDS fragment tile(s) [RT][Kb][64][4]
     const float* W;   // packed weights for this column block (out = N, in = 16*Kb)
     int Kb;
 };
 
-template <int NI, int NSEG, class Epi>
-__device__ __forceinline__ void tile_linear_seg(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
-                                                Epi&& epi) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+template <int RT, int NI>
+struct LinFrag {
+    floatx4 a[RT];
+    floatx4 b[NI];
+};
+
+// NI column blocks nb0, nb0+kWaves, ... of this wave (all valid), RT row tiles, all segments.
+template <int NSEG, int RT, int NI, int D, class Epi>
+__device__ __forceinline__ void linear_blocks(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, int nb0,
+                                              Epi&& epi) {
+    const int lane = threadIdx.x & 63;
+    constexpr bool kSplit = (NI * RT == 1);   // a lone chain would pay the 40-cycle dependent-MFMA latency
+    floatx4 acc[NI][RT];
+    floatx4 acc2 = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int col = (nb0 + i * kWaves) * 16 + (lane & 15);
+        const float b = (bias != nullptr && col < N) ? bias[col] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[i][rt] = floatx4{b, b, b, b};
+    }
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        const int Kb = seg[s].Kb;
+        const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(seg[s].X) + lane;
+        const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(seg[s].W) + lane + (size_t)nb0 * Kb * 64;
+        const size_t wstride = (size_t)kWaves * Kb * 64;   // between this wave's column blocks
+        pipelined_k<D>(
+            Kb,
+            [&](int kb) {
+                LinFrag<RT, NI> f;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) f.b[i] = W4[i * wstride + (size_t)kb * 64];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) f.a[rt] = X4[(rt * Kb + kb) * 64];
+                return f;
+            },
+            [&](const LinFrag<RT, NI>& f) {
+                if constexpr (kSplit) {
+                    acc[0][0] = mfma16(f.a[0][0], f.b[0][0], acc[0][0]);
+                    acc2 = mfma16(f.a[0][1], f.b[0][1], acc2);
+                    acc[0][0] = mfma16(f.a[0][2], f.b[0][2], acc[0][0]);
+                    acc2 = mfma16(f.a[0][3], f.b[0][3], acc2);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < NI; ++i)
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) acc[i][rt] = mfma16(f.a[rt][j], f.b[i][j], acc[i][rt]);
+                }
+            });
+    }
+    if constexpr (kSplit) acc[0][0] += acc2;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) epi(rt, nb0 + i * kWaves, acc[i][rt]);
+}
+
+// Each wave owns column blocks nb = wave, wave+kWaves, ...; two are kept in flight where two exist (independent
+// MFMA chains: 16x16x4 f32 issues every 32 cycles but a dependent one needs 40), the odd last one runs alone.
+// epi(rt, nb, acc): lane holds out[row = 16*rt + 4*(lane>>4) + r][col = nb*16 + (lane&15)], r = 0..3.
+template <int RT, int NSEG, class Epi>
+__device__ __forceinline__ void tile_linear_g(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Epi&& epi) {
+    const int wave = threadIdx.x >> 6;
     const int Nb = (N + 15) >> 4;
-    for (int nb0 = wave; nb0 < Nb; nb0 += kWaves * NI) {
-        floatx4 acc[NI];
-        int nbc[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int nb = nb0 + i * kWaves;
-            nbc[i] = nb < Nb ? nb : Nb - 1;
-            const int col = nb * 16 + (lane & 15);
-            const float b = (bias != nullptr && col < N) ? bias[col] : 0.f;
-            acc[i] = floatx4{b, b, b, b};
-        }
-#pragma unroll
-        for (int s = 0; s < NSEG; ++s) {
-            const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(seg[s].X) + lane;
-            const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(seg[s].W) + lane;
-            const int Kb = seg[s].Kb;
-            for (int kb = 0; kb < Kb; ++kb) {
-                const floatx4 a4 = X4[kb * 64];
-                floatx4 b4[NI];
-#pragma unroll
-                for (int i = 0; i < NI; ++i) b4[i] = W4[((size_t)nbc[i] * Kb + kb) * 64];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) acc[i] = mfma16(a4[j], b4[i][j], acc[i]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int nb = nb0 + i * kWaves;
-            if (nb < Nb) epi(nb, acc[i]);
-        }
+    constexpr int D = 2;
+    for (int nb0 = wave; nb0 < Nb; nb0 += 2 * kWaves) {
+        if (nb0 + kWaves < Nb) linear_blocks<NSEG, RT, 2, D>(seg, bias, N, nb0, epi);
+        else linear_blocks<NSEG, RT, 1, D>(seg, bias, N, nb0, epi);
     }
 }
 
-// Two outputs sharing one column index (mean / raw-std rows of a Gaussian head, or d/dx and d/dh of the
-// GRU): out0 = sum_s X_s W0_s^T + bias0, out1 = sum_s X_s W1_s^T + bias1.  The two chains are
-// independent, which also hides the MFMA dependent-issue latency.
+// single-segment convenience forms
+template <int RT, int NI_UNUSED, class Epi>
+__device__ __forceinline__ void tile_linear(const float* __restrict__ X, int Kb, const float* __restrict__ Wp,
+                                            const float* __restrict__ bias, int N, Epi&& epi) {
+    const Seg seg[1] = {{X, Wp, Kb}};
+    tile_linear_g<RT, 1>(seg, bias, N, epi);
+}
+
+template <int NI_UNUSED, int NSEG, class Epi>
+__device__ __forceinline__ void tile_linear_seg(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
+                                                Epi&& epi) {
+    tile_linear_g<1, NSEG>(seg, bias, N, [&](int, int nb, floatx4 acc) { epi(nb, acc); });
+}
+
+// Two outputs sharing one column index (mean / raw-std rows of a Gaussian head): out0 = sum_s X_s W0_s^T + bias0,
+// out1 = sum_s X_s W1_s^T + bias1 (a null W0/W1 means the segment does not feed that output).  The two chains
+// are independent, which also hides the MFMA dependent-issue latency.
 struct Seg2 {
     const float* X;
-    const float* W0;  // may be nullptr: segment does not feed output 0
-    const float* W1;  // may be nullptr: segment does not feed output 1
+    const float* W0;
+    const float* W1;
     int Kb;
+};
+
+struct DualFrag {
+    floatx4 a, p, q;
 };
 
 template <int NSEG, class Epi>
@@ -232,26 +283,25 @@ __device__ __forceinline__ void tile_linear_dual(const Seg2 (&seg)[NSEG], const 
             const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(seg[s].X) + lane;
             const int Kb = seg[s].Kb;
             const size_t off = (size_t)nb * Kb * 64 + lane;
+            const floatx4* __restrict__ W0 = reinterpret_cast<const floatx4*>(seg[s].W0) + off;
+            const floatx4* __restrict__ W1 = reinterpret_cast<const floatx4*>(seg[s].W1) + off;
             if (seg[s].W0 != nullptr && seg[s].W1 != nullptr) {
-                const floatx4* __restrict__ W0 = reinterpret_cast<const floatx4*>(seg[s].W0) + off;
-                const floatx4* __restrict__ W1 = reinterpret_cast<const floatx4*>(seg[s].W1) + off;
-                for (int kb = 0; kb < Kb; ++kb) {
-                    const floatx4 a4 = X4[kb * 64], p4 = W0[kb * 64], q4 = W1[kb * 64];
+                pipelined_k<2>(
+                    Kb, [&](int kb) { return DualFrag{X4[kb * 64], W0[kb * 64], W1[kb * 64]}; },
+                    [&](const DualFrag& f) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc0 = mfma16(a4[j], p4[j], acc0);
-                        acc1 = mfma16(a4[j], q4[j], acc1);
-                    }
-                }
+                        for (int j = 0; j < 4; ++j) {
+                            acc0 = mfma16(f.a[j], f.p[j], acc0);
+                            acc1 = mfma16(f.a[j], f.q[j], acc1);
+                        }
+                    });
             } else if (seg[s].W0 != nullptr) {
-                const floatx4* __restrict__ W0 = reinterpret_cast<const floatx4*>(seg[s].W0) + off;
                 for (int kb = 0; kb < Kb; ++kb) {
                     const floatx4 a4 = X4[kb * 64], p4 = W0[kb * 64];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc0 = mfma16(a4[j], p4[j], acc0);
                 }
             } else if (seg[s].W1 != nullptr) {
-                const floatx4* __restrict__ W1 = reinterpret_cast<const floatx4*>(seg[s].W1) + off;
                 for (int kb = 0; kb < Kb; ++kb) {
                     const floatx4 a4 = X4[kb * 64], q4 = W1[kb * 64];
 #pragma unroll
@@ -270,6 +320,10 @@ __device__ __forceinline__ void tile_linear_dual(const Seg2 (&seg)[NSEG], const 
 struct GruW {
     const float *w_ir, *w_iz, *w_in, *w_hr, *w_hz, *w_hn;   // packed (Be, Be) each
     const float *b_ih, *b_hh;                               // [3*Be]
+};
+
+struct GruFrag {
+    floatx4 ax, ah, bir, biz, bin, bhr, bhz, bhn;
 };
 
 template <class Epi>
@@ -295,20 +349,23 @@ __device__ __forceinline__ void gru_tile(const float* __restrict__ X, const floa
         const floatx4* __restrict__ Whr = reinterpret_cast<const floatx4*>(w.w_hr) + off;
         const floatx4* __restrict__ Whz = reinterpret_cast<const floatx4*>(w.w_hz) + off;
         const floatx4* __restrict__ Whn = reinterpret_cast<const floatx4*>(w.w_hn) + off;
-        for (int kb = 0; kb < Kb; ++kb) {
-            const floatx4 ax = X4[kb * 64], ah = H4[kb * 64];
-            const floatx4 bir = Wir[kb * 64], biz = Wiz[kb * 64], bin = Win[kb * 64];
-            const floatx4 bhr = Whr[kb * 64], bhz = Whz[kb * 64], bhn = Whn[kb * 64];
+        pipelined_k<1>(
+            Kb,
+            [&](int kb) {
+                return GruFrag{X4[kb * 64], H4[kb * 64], Wir[kb * 64], Wiz[kb * 64], Win[kb * 64],
+                               Whr[kb * 64], Whz[kb * 64], Whn[kb * 64]};
+            },
+            [&](const GruFrag& f) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                R = mfma16(ax[j], bir[j], R);
-                Z = mfma16(ax[j], biz[j], Z);
-                NI = mfma16(ax[j], bin[j], NI);
-                NH = mfma16(ah[j], bhn[j], NH);
-                R = mfma16(ah[j], bhr[j], R);
-                Z = mfma16(ah[j], bhz[j], Z);
-            }
-        }
+                for (int j = 0; j < 4; ++j) {
+                    R = mfma16(f.ax[j], f.bir[j], R);
+                    Z = mfma16(f.ax[j], f.biz[j], Z);
+                    NI = mfma16(f.ax[j], f.bin[j], NI);
+                    NH = mfma16(f.ah[j], f.bhn[j], NH);
+                    R = mfma16(f.ah[j], f.bhr[j], R);
+                    Z = mfma16(f.ah[j], f.bhz[j], Z);
+                }
+            });
         epi(nb, R, Z, NI, NH);
     }
 }
@@ -316,6 +373,10 @@ __device__ __forceinline__ void gru_tile(const float* __restrict__ X, const floa
 // Backward of the two GRU matmuls: DX = W_ir^T dR + W_iz^T dZ + W_in^T dNI, DH = W_hr^T dR + W_hz^T dZ + W_hn^T dNH
 struct GruWT {
     const float *wt_ir, *wt_iz, *wt_in, *wt_hr, *wt_hz, *wt_hn;   // packed transposes (Be, Be)
+};
+
+struct GruBwdFrag {
+    floatx4 ar, az, ai, ah, bir, biz, bin, bhr, bhz, bhn;
 };
 
 template <class Epi>
@@ -330,6 +391,7 @@ __device__ __forceinline__ void gru_tile_bwd(const float* __restrict__ dR, const
     const floatx4* __restrict__ H4 = reinterpret_cast<const floatx4*>(dNH) + lane;
     for (int nb = wave; nb < Nb; nb += kWaves) {
         floatx4 DX = floatx4{0.f, 0.f, 0.f, 0.f}, DH = floatx4{0.f, 0.f, 0.f, 0.f};
+        floatx4 DX2 = DX, DH2 = DH;   // second chain per output: consecutive MFMAs stay independent
         const size_t off = (size_t)nb * Kb * 64 + lane;
         const floatx4* __restrict__ Wir = reinterpret_cast<const floatx4*>(w.wt_ir) + off;
         const floatx4* __restrict__ Wiz = reinterpret_cast<const floatx4*>(w.wt_iz) + off;
@@ -337,21 +399,24 @@ __device__ __forceinline__ void gru_tile_bwd(const float* __restrict__ dR, const
         const floatx4* __restrict__ Whr = reinterpret_cast<const floatx4*>(w.wt_hr) + off;
         const floatx4* __restrict__ Whz = reinterpret_cast<const floatx4*>(w.wt_hz) + off;
         const floatx4* __restrict__ Whn = reinterpret_cast<const floatx4*>(w.wt_hn) + off;
-        for (int kb = 0; kb < Kb; ++kb) {
-            const floatx4 ar = R4[kb * 64], az = Z4[kb * 64], ai = I4[kb * 64], ah = H4[kb * 64];
-            const floatx4 bir = Wir[kb * 64], biz = Wiz[kb * 64], bin = Win[kb * 64];
-            const floatx4 bhr = Whr[kb * 64], bhz = Whz[kb * 64], bhn = Whn[kb * 64];
+        pipelined_k<1>(
+            Kb,
+            [&](int kb) {
+                return GruBwdFrag{R4[kb * 64], Z4[kb * 64], I4[kb * 64], H4[kb * 64], Wir[kb * 64], Wiz[kb * 64],
+                                  Win[kb * 64], Whr[kb * 64], Whz[kb * 64], Whn[kb * 64]};
+            },
+            [&](const GruBwdFrag& f) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                DX = mfma16(ar[j], bir[j], DX);
-                DH = mfma16(ar[j], bhr[j], DH);
-                DX = mfma16(az[j], biz[j], DX);
-                DH = mfma16(az[j], bhz[j], DH);
-                DX = mfma16(ai[j], bin[j], DX);
-                DH = mfma16(ah[j], bhn[j], DH);
-            }
-        }
-        epi(nb, DX, DH);
+                for (int j = 0; j < 4; ++j) {
+                    DX = mfma16(f.ar[j], f.bir[j], DX);
+                    DH = mfma16(f.ar[j], f.bhr[j], DH);
+                    DX2 = mfma16(f.az[j], f.biz[j], DX2);
+                    DH2 = mfma16(f.az[j], f.bhz[j], DH2);
+                    DX = mfma16(f.ai[j], f.bin[j], DX);
+                    DH = mfma16(f.ah[j], f.bhn[j], DH);
+                }
+            });
+        epi(nb, DX + DX2, DH + DH2);
     }
 }
 

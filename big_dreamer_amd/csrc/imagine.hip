@@ -106,11 +106,11 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
     float* mean_s = af + d.Kb_a * kFragFloats;    // [16][A]
     float* std_s = mean_s + 16 * A;               // [16][A]
     float* lp_rj = std_s + 16 * A;                // [16][A]
-    float* part = lp_rj + 16 * A;                 // [4][16][A][3]
+    float* part = lp_rj + 16 * A;                 // [kWaves][16][A][3]
 
     load_tile_concat<1>(h_cur, d.Kb_h, row0, a.N, a.start_feat, F, a.Be, nullptr, 0, 0);
     load_tile_concat<1>(sf, d.Kb_s, row0, a.N, a.start_feat + a.Be, F, a.S, nullptr, 0, 0);
-    __syncthreads();
+    lds_barrier();
 
     const GruW gw{a.w_ir, a.w_iz, a.w_in, a.w_hr, a.w_hz, a.w_hn, a.b_ih, a.b_hh};
     const size_t act_stride = (size_t)a.Hm * a.N * a.Hd;
@@ -126,17 +126,17 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         // ---- actor hidden layers ----
         {
             const Seg segs[2] = {{h_cur, a.w_a0h, d.Kb_h}, {sf, a.w_a0s, d.Kb_s}};
-            tile_linear_seg<4, 2>(segs, a.b_a[0], a.Hd, hidden_epi(bufA, a.sv_actor, tn, a.Hd));
+            tile_linear_seg<kNI, 2>(segs, a.b_a[0], a.Hd, hidden_epi(bufA, a.sv_actor, tn, a.Hd));
         }
-        __syncthreads();
+        lds_barrier();
         {
             float* src = bufA;
             float* dst = bufB;
             for (int l = 1; l < 4; ++l) {
                 const Seg segs[1] = {{src, a.w_a[l - 1], d.Kb_hd}};
-                tile_linear_seg<4, 1>(segs, a.b_a[l], a.Hd,
+                tile_linear_seg<kNI, 1>(segs, a.b_a[l], a.Hd,
                                       hidden_epi(dst, a.sv_actor ? a.sv_actor + l * act_stride : nullptr, tn, a.Hd));
-                __syncthreads();
+                lds_barrier();
                 float* tmp = src; src = dst; dst = tmp;
             }
             // after 3 layers the activations of layer 3 are in bufB (A->B, B->A, A->B)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                 }
             });
         }
-        __syncthreads();
+        lds_barrier();
         // ---- entropy: n_samples draws per (row, action dim); thread = (row, sample lane) ----
         {
             const int row = threadIdx.x & 15, sl = threadIdx.x >> 4;   // 16 sample lanes
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                 float lp = 0.f, dm = 0.f, ds = 0.f;
                 if (grow < a.N) {
                     const float mean = mean_s[row * A + j], sd = std_s[row * A + j];
-                    for (int k = sl; k < a.n_samples; k += 16) {
+                    for (int k = sl; k < a.n_samples; k += kThreads / 16) {
                         const float e = a.eps_entropy[(((size_t)t * a.n_samples + k) * a.N + grow) * A + j];
                         float l1, d1, d2;
                         entropy_sample(mean, sd, e, l1, d1, d2);
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         for (int i = threadIdx.x; i < 16 * A; i += blockDim.x) {
             const int row = i / A, j = i - row * A, grow = row0 + row;
             float lp = 0.f, dm = 0.f, ds = 0.f;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                 st[3 * A] = -ds * inv_ns;     // d entropy / d std
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (threadIdx.x < 16 && row0 + threadIdx.x < a.N) {
             float s = 0.f;
             for (int j = 0; j < A; ++j) s += lp_rj[threadIdx.x * A + j];
@@ -219,9 +219,9 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         // ---- embed ----
         {
             const Seg segs[2] = {{sf, a.w_embed_s, d.Kb_s}, {af, a.w_embed_a, d.Kb_a}};
-            tile_linear_seg<4, 2>(segs, a.b_embed, a.Be, hidden_epi(xf, a.sv_x, tn, a.Be));
+            tile_linear_seg<kNI, 2>(segs, a.b_embed, a.Be, hidden_epi(xf, a.sv_x, tn, a.Be));
         }
-        __syncthreads();
+        lds_barrier();
         // ---- GRU ----
         gru_tile(xf, h_cur, d.Kb_h, a.Be, gw, [&](int nb, floatx4 R, floatx4 Z, floatx4 NI, floatx4 NH) {
             const int col = nb * 16 + (lane & 15);
@@ -243,13 +243,13 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                 }
             }
         });
-        __syncthreads();
+        lds_barrier();
         // ---- prior ----
         {
             const Seg segs[1] = {{h_nxt, a.w_p1, d.Kb_h}};
-            tile_linear_seg<4, 1>(segs, a.b_p1, a.Hd, hidden_epi(bufA, a.sv_p, tn, a.Hd));
+            tile_linear_seg<kNI, 1>(segs, a.b_p1, a.Hd, hidden_epi(bufA, a.sv_p, tn, a.Hd));
         }
-        __syncthreads();
+        lds_barrier();
         {
             const Seg2 segs[1] = {{bufA, a.w_p2m, a.w_p2s, d.Kb_hd}};
             tile_linear_dual<1>(segs, a.b_p2, a.b_p2 + a.S, a.S, [&](int nb, floatx4 Mn, floatx4 Rw) {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                 }
             });
         }
-        __syncthreads();
+        lds_barrier();
         float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
     }
 }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
 
     for (int i = threadIdx.x; i < nh; i += blockDim.x) dhc[i] = 0.f;
     for (int i = threadIdx.x; i < 16 * a.S; i += blockDim.x) ds_plain[i] = 0.f;
-    __syncthreads();
+    lds_barrier();
 
     const GruWT gw{a.wt_ir, a.wt_iz, a.wt_in, a.wt_hr, a.wt_hz, a.wt_hn};
     const size_t act_stride = (size_t)a.Hm * a.N * a.Hd;
@@ -325,15 +325,15 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
             dM[frag_idx(r, k)] = dm;
             dRaw[frag_idx(r, k)] = dr;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- 2: prior hidden ----
         {
             const Seg segs[2] = {{dM, a.wt_p2m, d.Kb_s}, {dRaw, a.wt_p2s, d.Kb_s}};
-            tile_linear_seg<4, 2>(segs, nullptr, a.Hd, dpre_epi(dP, a.sv_p, nullptr, tn, a.Hd));
+            tile_linear_seg<kNI, 2>(segs, nullptr, a.Hd, dpre_epi(dP, a.sv_p, nullptr, tn, a.Hd));
         }
-        __syncthreads();
+        lds_barrier();
         // ---- 3: total d belief_{t+1}; GRU gates ----
-        tile_linear<1, 4>(dP, d.Kb_hd, a.wt_p1, nullptr, a.Be, [&](int, int nb, floatx4 acc) {
+        tile_linear<1, kNI>(dP, d.Kb_hd, a.wt_p1, nullptr, a.Be, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
                 dhc[off] = carry;
             }
         });
-        __syncthreads();
+        lds_barrier();
         // ---- 4: through W_ih / W_hh ----
         gru_tile_bwd(dR, dZ, dNI, dNH, d.Kb_h, a.Be, gw, [&](int nb, floatx4 DX, floatx4 DH) {
             const int col = nb * 16 + (lane & 15);
@@ -373,9 +373,9 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
                 dE[off] = de;
             }
         });
-        __syncthreads();
+        lds_barrier();
         // ---- 5: embed layer -> d state_t (carry) and d action_t -> actor output gradients ----
-        tile_linear<1, 4>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
+        tile_linear<1, kNI>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
                 if (col < a.S) ds_plain[row * a.S + col] = (row0 + row < a.N) ? acc[r] : 0.f;
             }
         });
-        tile_linear<1, 4>(dE, d.Kb_h, a.wt_embed_a, nullptr, A, [&](int, int nb, floatx4 acc) {
+        tile_linear<1, kNI>(dE, d.Kb_h, a.wt_embed_a, nullptr, A, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -406,23 +406,23 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
                 dAr[acc_frag_off(nb, lane, r)] = gr;
             }
         });
-        __syncthreads();
+        lds_barrier();
         // ---- 6: actor MLP backward (input detached: no gradient below layer 0) ----
         {
             const Seg segs[2] = {{dAm, a.wt_a4m, d.Kb_a}, {dAr, a.wt_a4s, d.Kb_a}};
-            tile_linear_seg<4, 2>(segs, nullptr, a.Hd,
+            tile_linear_seg<kNI, 2>(segs, nullptr, a.Hd,
                                   dpre_epi(bufA, a.sv_actor + 3 * act_stride, a.d_actor_pre + 3 * act_stride, tn, a.Hd));
         }
-        __syncthreads();
+        lds_barrier();
         {
             float* src = bufA;
             float* dst = bufB;
             for (int l = 2; l >= 0; --l) {
                 const Seg segs[1] = {{src, a.wt_a[l], d.Kb_hd}};
-                tile_linear_seg<4, 1>(segs, nullptr, a.Hd,
+                tile_linear_seg<kNI, 1>(segs, nullptr, a.Hd,
                                       dpre_epi(l > 0 ? dst : nullptr, a.sv_actor + l * act_stride,
                                                a.d_actor_pre + l * act_stride, tn, a.Hd));
-                __syncthreads();
+                lds_barrier();
                 float* tmp = src; src = dst; dst = tmp;
             }
         }
@@ -445,7 +445,7 @@ int bd_imagine_forward(const bd_imagine_fwd_args* a, void* stream) {
     BD_REQUIRE(a->start_feat && a->eps_action && a->eps_entropy && a->eps_prior, "bd_imagine_forward: missing inputs");
     BD_REQUIRE(a->feat && a->prior_std && a->entropy && a->action, "bd_imagine_forward: missing outputs");
     const ImgDims d(a->Be, a->S, a->A, a->Hd);
-    const size_t lds = ((size_t)(3 * d.Kb_h + 2 * d.Kb_hd + d.Kb_s + d.Kb_a) * kFragFloats + (size_t)(3 * 16 + 4 * 16 * 3) * a->A) *
+    const size_t lds = ((size_t)(3 * d.Kb_h + 2 * d.Kb_hd + d.Kb_s + d.Kb_a) * kFragFloats + (size_t)(3 * 16 + kWaves * 16 * 3) * a->A) *
                        sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_imagine_forward: needs %zu B of LDS", lds);
     if (lds > 64 * 1024 && allow_big_lds(imagine_fwd_kernel)) return -1;

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, in
     float* cur = smem;                                   // inputs of even layers
     float* nxt = smem + (size_t)RT * KbA * kFragFloats;  // inputs of odd layers
     load_tile_concat<RT>(cur, cdiv(a.w0 + a.w1, 16), row0, a.M, a.in0, a.ld0, a.w0, a.in1, a.ld1, a.w1);
-    __syncthreads();
+    lds_barrier();
     for (int l = 0; l < a.n_layers; ++l) {
         const bd_layer L = a.layer[l];
         const bool last = (l == a.n_layers - 1);
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, in
                 }
             }
         });
-        __syncthreads();
+        lds_barrier();
         float* t = cur; cur = nxt; nxt = t;
     }
 }
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_kernel(bd_mlp_bwd_args a, in
             cur[(r >> 4) * Kb * kFragFloats + frag_idx(r & 15, k)] = v;
         }
     }
-    __syncthreads();
+    lds_barrier();
     for (int l = a.n_layers - 1; l >= 1; --l) {
         const bd_layer_bwd L = a.layer[l];       // contraction over this layer's outputs (N) -> its inputs (K)
         const bd_layer_bwd P = a.layer[l - 1];   // whose outputs those inputs are
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_kernel(bd_mlp_bwd_args a, in
                 nxt[(rt * Nb + nb) * kFragFloats + ((c >> 2) * 16 + row) * 4 + (c & 3)] = v;
             }
         });
-        __syncthreads();
+        lds_barrier();
         float* t = cur; cur = nxt; nxt = t;
     }
     if (a.din0 != nullptr || a.din1 != nullptr) {

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kThreads) void observe_fwd_kernel(bd_observe_fwd_ar
         const int r = i / a.S, k = i - r * a.S;
         s_plain[i] = (row0 + r < a.B) ? a.init_state[(size_t)(row0 + r) * a.S + k] : 0.f;
     }
-    __syncthreads();
+    lds_barrier();
 
     const GruW gw{a.w_ir, a.w_iz, a.w_in, a.w_hr, a.w_hz, a.w_hn, a.b_ih, a.b_hh};
 
@@ -63,11 +63,11 @@ __global__ __launch_bounds__(kThreads) void observe_fwd_kernel(bd_observe_fwd_ar
             const int grow = row0 + r;
             af[frag_idx(r, k)] = (grow < a.B && k < a.A) ? a.actions[(tb + grow) * a.A + k] : 0.f;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- B: x = ELU(W_e [s~; a] + b_e) ----
         {
             const Seg segs[2] = {{sf, a.w_embed_s, d.Kb_s}, {af, a.w_embed_a, d.Kb_a}};
-            tile_linear_seg<4, 2>(segs, a.b_embed, a.Be, [&](int nb, floatx4 acc) {
+            tile_linear_seg<kNI, 2>(segs, a.b_embed, a.Be, [&](int nb, floatx4 acc) {
                 const int col = nb * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kThreads) void observe_fwd_kernel(bd_observe_fwd_ar
                 }
             });
         }
-        __syncthreads();
+        lds_barrier();
         // ---- C: GRU ----
         gru_tile(xf, h_cur, d.Kb_h, a.Be, gw, [&](int nb, floatx4 R, floatx4 Z, floatx4 NI, floatx4 NH) {
             const int col = nb * 16 + (lane & 15);
@@ -100,9 +100,9 @@ __global__ __launch_bounds__(kThreads) void observe_fwd_kernel(bd_observe_fwd_ar
                 }
             }
         });
-        __syncthreads();
+        lds_barrier();
         // ---- D: posterior hidden ----
-        tile_linear<1, 4>(h_nxt, d.Kb_h, a.w_q1h, a.b_q1, a.Hd, [&](int, int nb, floatx4 acc) {
+        tile_linear<1, kNI>(h_nxt, d.Kb_h, a.w_q1h, a.b_q1, a.Hd, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void observe_fwd_kernel(bd_observe_fwd_ar
                 if (ok && a.sv_q) a.sv_q[(tb + grow) * a.Hd + col] = v;
             }
         });
-        __syncthreads();
+        lds_barrier();
         // ---- E: posterior mean / std / sample ----
         {
             const Seg2 segs[1] = {{qf, a.w_q2m, a.w_q2s, d.Kb_hd}};
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void observe_fwd_kernel(bd_observe_fwd_ar
                 }
             });
         }
-        __syncthreads();
+        lds_barrier();
         float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
     }
 }
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void observe_bwd_kernel(bd_observe_bwd_ar
 
     for (int i = threadIdx.x; i < nh; i += blockDim.x) dhc[i] = 0.f;
     for (int i = threadIdx.x; i < 16 * a.S; i += blockDim.x) ds_plain[i] = 0.f;
-    __syncthreads();
+    lds_barrier();
 
     const GruWT gw{a.wt_ir, a.wt_iz, a.wt_in, a.wt_hr, a.wt_hz, a.wt_hn};
 
@@ -186,11 +186,11 @@ __global__ __launch_bounds__(kThreads) void observe_bwd_kernel(bd_observe_bwd_ar
             dM[frag_idx(r, k)] = dm;
             dRaw[frag_idx(r, k)] = dr;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- 2: d q (posterior hidden) ----
         {
             const Seg segs[2] = {{dM, a.wt_q2m, d.Kb_s}, {dRaw, a.wt_q2s, d.Kb_s}};
-            tile_linear_seg<4, 2>(segs, nullptr, a.Hd, [&](int nb, floatx4 acc) {
+            tile_linear_seg<kNI, 2>(segs, nullptr, a.Hd, [&](int nb, floatx4 acc) {
                 const int col = nb * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -204,9 +204,9 @@ __global__ __launch_bounds__(kThreads) void observe_bwd_kernel(bd_observe_bwd_ar
                 }
             });
         }
-        __syncthreads();
+        lds_barrier();
         // ---- 3: total d belief_{t+1}, GRU gate gradients ----
-        tile_linear<1, 4>(dQ, d.Kb_hd, a.wt_q1h, nullptr, a.Be, [&](int, int nb, floatx4 acc) {
+        tile_linear<1, kNI>(dQ, d.Kb_hd, a.wt_q1h, nullptr, a.Be, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kThreads) void observe_bwd_kernel(bd_observe_bwd_ar
                 dhc[off] = carry;
             }
         });
-        __syncthreads();
+        lds_barrier();
         // ---- 4: through W_ih / W_hh ----
         gru_tile_bwd(dR, dZ, dNI, dNH, d.Kb_h, a.Be, gw, [&](int nb, floatx4 DX, floatx4 DH) {
             const int col = nb * 16 + (lane & 15);
@@ -252,9 +252,9 @@ __global__ __launch_bounds__(kThreads) void observe_bwd_kernel(bd_observe_bwd_ar
                 dE[off] = de;
             }
         });
-        __syncthreads();
+        lds_barrier();
         // ---- 5: d posterior_state_t through the embed layer and the nonterminal mask ----
-        tile_linear<1, 4>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
+        tile_linear<1, kNI>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kThreads) void observe_bwd_kernel(bd_observe_bwd_ar
                 }
             }
         });
-        __syncthreads();
+        lds_barrier();
     }
 }
 
