@@ -16,6 +16,21 @@ namespace bd {
 
 constexpr int kMaxA = 64;
 
+// Diagnostic build only (-DBD_STAMPS): workgroup 0 / thread 0 records s_memtime at the phase boundaries of one
+// step into a buffer that nothing else reads (bd_debug_stamps copies it out).  Never defined in the shipped .so.
+#ifdef BD_STAMPS
+__device__ unsigned long long g_stamps[64];
+#define BD_STAMP(slot)                                                                      \
+    do {                                                                                    \
+        if (blockIdx.x == BD_STAMP_WG && threadIdx.x == 0 && t == 3) g_stamps[slot] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#ifndef BD_STAMP_WG
+#define BD_STAMP_WG 0
+#endif
+#else
+#define BD_STAMP(slot)
+#endif
+
 struct ImgDims {
     int Kb_h, Kb_s, Kb_a, Kb_hd;
     __host__ __device__ ImgDims(int Be, int S, int A, int Hd)
@@ -123,12 +138,15 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
 
     for (int t = 0; t < a.Hm; ++t) {
         const size_t tn = (size_t)t * a.N;
+        BD_STAMP(0);
         // ---- actor hidden layers ----
         {
             const Seg segs[2] = {{h_cur, a.w_a0h, d.Kb_h}, {sf, a.w_a0s, d.Kb_s}};
             tile_linear_seg<kNI, 2>(segs, a.b_a[0], a.Hd, hidden_epi(bufA, a.sv_actor, tn, a.Hd));
         }
+        BD_STAMP(1);
         lds_barrier();
+        BD_STAMP(2);
         {
             float* src = bufA;
             float* dst = bufB;
@@ -141,6 +159,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
             }
             // after 3 layers the activations of layer 3 are in bufB (A->B, B->A, A->B)
         }
+        BD_STAMP(3);
         // ---- actor output, action sample ----
         {
             const Seg2 segs[1] = {{bufB, a.w_a4m, a.w_a4s, d.Kb_hd}};
@@ -169,7 +188,9 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                 }
             });
         }
+        BD_STAMP(4);
         lds_barrier();
+        BD_STAMP(5);
         // ---- entropy: n_samples draws per (row, action dim); thread = (row, sample lane) ----
         {
             const int row = threadIdx.x & 15, sl = threadIdx.x >> 4;   // 16 sample lanes
@@ -216,12 +237,15 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
             for (int j = 0; j < A; ++j) s += lp_rj[threadIdx.x * A + j];
             a.entropy[tn + row0 + threadIdx.x] = -s * inv_ns;
         }
+        BD_STAMP(6);
         // ---- embed ----
         {
             const Seg segs[2] = {{sf, a.w_embed_s, d.Kb_s}, {af, a.w_embed_a, d.Kb_a}};
             tile_linear_seg<kNI, 2>(segs, a.b_embed, a.Be, hidden_epi(xf, a.sv_x, tn, a.Be));
         }
+        BD_STAMP(7);
         lds_barrier();
+        BD_STAMP(8);
         // ---- GRU ----
         gru_tile(xf, h_cur, d.Kb_h, a.Be, gw, [&](int nb, floatx4 R, floatx4 Z, floatx4 NI, floatx4 NH) {
             const int col = nb * 16 + (lane & 15);
@@ -243,13 +267,17 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                 }
             }
         });
+        BD_STAMP(9);
         lds_barrier();
+        BD_STAMP(10);
         // ---- prior ----
         {
             const Seg segs[1] = {{h_nxt, a.w_p1, d.Kb_h}};
             tile_linear_seg<kNI, 1>(segs, a.b_p1, a.Hd, hidden_epi(bufA, a.sv_p, tn, a.Hd));
         }
+        BD_STAMP(11);
         lds_barrier();
+        BD_STAMP(12);
         {
             const Seg2 segs[1] = {{bufA, a.w_p2m, a.w_p2s, d.Kb_hd}};
             tile_linear_dual<1>(segs, a.b_p2, a.b_p2 + a.S, a.S, [&](int nb, floatx4 Mn, floatx4 Rw) {
@@ -270,7 +298,9 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                 }
             });
         }
+        BD_STAMP(13);
         lds_barrier();
+        BD_STAMP(14);
         float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
     }
 }
@@ -433,6 +463,13 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
 
 extern "C" {
 using namespace bd;
+
+#ifdef BD_STAMPS
+// diagnostic: copy the s_memtime stamps out (synchronises the device)
+int bd_debug_stamps(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int bd_imagine_forward(const bd_imagine_fwd_args* a, void* stream) {
     BD_REQUIRE(a && a->N > 0 && a->Hm > 0 && a->Be > 0 && a->S > 0 && a->A > 0 && a->A <= kMaxA && a->Hd > 0 &&

@@ -1,0 +1,226 @@
+"""Dreamer agent with the reference's call surface (src/dreamer.py, src/planet.py) on the HIP engine.
+
+Kept surface: ``Dreamer(params, env)``, ``train_step() -> Dict[str, float]``,
+``imagine_ahead``, ``get_action``, ``update_critic``, ``update_belief_and_act``, ``buffer.append/sample``,
+``eval()/train()``, ``observation_model(h, s)``, module attributes with reference ``state_dict`` names, ``load``
+of the reference's checkpoint dict (src/planet.py:103-114), and the module function ``lambda_return``.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _cabi as cabi
+from .engine import DreamerEngine
+from .memory import ExperienceReplay
+from .models import ActorModel, DenseModel, TransitionModel, encoder_for
+from .synth import Dims
+
+
+def _hp_from_params(params: Dict[str, Any]) -> Dict[str, float]:
+    ac = params["ActorCritic"]
+    return dict(
+        kl_balance=params["kl_balance"], kl_loss_weight=params["kl_loss_weight"], free_nats=params["free_nats"],
+        grad_clip_norm=params["grad_clip_norm"], discount=params["discount"], disclam=params["disclam"],
+        model_learning_rate=params["model_learning_rate"], actor_learning_rate=ac["actor_learning_rate"],
+        value_learning_rate=ac["value_learning_rate"], adam_epsilon=params["adam_epsilon"],
+        weight_decay=params["weight_decay"], entropy_weight=ac["entropy_weight"], polyak_avg=ac["polyak_avg"])
+
+
+class Dreamer:
+    """Drop-in for the reference's ``Dreamer`` (state observations, Gaussian latents)."""
+
+    def __init__(self, params: Dict[str, Any], env, device: Optional[str] = None, world_size: int = 1,
+                 process_group=None):
+        if params.get("pixel_observation", False):
+            raise NotImplementedError("pixel observations (conv encoder/decoder) are not in this build's scope yet")
+        if params.get("latent_distribution", "Gaussian") != "Gaussian":
+            raise NotImplementedError("Categorical latents: the reference path crashes at HEAD (parity unpinned)")
+        if params["ActorCritic"]["gradient_mixing"] != -1:
+            raise NotImplementedError("gradient_mixing not yet implemented ")      # as src/dreamer.py:339
+        if params.get("use_discount", False):
+            raise NotImplementedError("use_discount=True is off the default hot path")
+        if params.get("disable_cuda", False) or not torch.cuda.is_available():
+            raise RuntimeError("big_dreamer_amd runs on MI355X only: there is no CPU path (disable_cuda=True is the "
+                               "reference's own CPU mode)")
+        self.env = env
+        self.params = params
+        self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        self.belief_size, self.state_size = params["belief_size"], params["state_size"]
+        self.action_size, self.hidden_size = env.action_size, params["hidden_size"]
+        self.embedding_size = params["embedding_size"]
+        self.batch_size, self.seq_len = params["batch_size"], params["seq_len"]
+        self.planning_horizon = params["planning_horizon"]
+        self.action_noise = params["action_noise"]
+        self.action_repeat = params["action_repeat"]
+        self.seed_steps = params["seed_steps"]
+        self.pixel_observation = False
+        self.dims = Dims(B=self.batch_size, L=self.seq_len, H=self.planning_horizon, Be=self.belief_size,
+                         S=self.state_size, Hd=self.hidden_size, E=self.embedding_size, A=self.action_size,
+                         O=env.observation_size)
+        self.engine = DreamerEngine(self.dims, _hp_from_params(params), self.device, world_size=world_size,
+                                    process_group=process_group)
+        e = self.engine
+        # PyTorch-default initialisation happens in the nn.Modules below (their parameters alias the engine's
+        # flat buffers), so seeding torch before construction reproduces a run (src/main.py:56-58).
+        init = {}
+        feat = self.belief_size + self.state_size
+        for mod, build in (
+            ("transition_model", lambda: _ref_init_transition(self.dims)),
+            ("observation_model", lambda: _ref_init_dense(feat, self.hidden_size, env.observation_size)),
+            ("reward_model", lambda: _ref_init_dense(feat, self.hidden_size, 1)),
+            ("encoder", lambda: _ref_init_dense(env.observation_size, self.hidden_size, self.embedding_size)),
+            ("actor", lambda: _ref_init_dense(feat, self.hidden_size, 2 * self.action_size)),
+            ("critic", lambda: _ref_init_dense(feat, self.hidden_size, 1)),
+        ):
+            init[mod] = {k: v.detach().numpy() for k, v in build().state_dict().items()}
+        init["critic_target"] = init["critic"]                # copy.deepcopy(self.critic), src/dreamer.py:50
+        e.load_params(init)
+        for g in ("model", "actor", "critic", "critic_target"):
+            e.pack(g)
+        self.transition_model = TransitionModel(self.belief_size, self.state_size, self.action_size, self.hidden_size,
+                                                self.embedding_size, engine=e)
+        self.observation_model = DenseModel(feat, self.hidden_size, env.observation_size, engine=e,
+                                            module="observation_model", prefix="obs")
+        self.reward_model = DenseModel(feat, self.hidden_size, 1, engine=e, module="reward_model", prefix="rew")
+        self.encoder = encoder_for(e, env.observation_size, self.hidden_size, self.embedding_size)
+        self.actor = ActorModel(self.belief_size, self.state_size, self.hidden_size, self.action_size, engine=e)
+        self.critic = DenseModel(feat, self.hidden_size, 1, engine=e, module="critic", prefix="cri")
+        self.critic_target = DenseModel(feat, self.hidden_size, 1, engine=e, module="critic_target", prefix="tgt")
+        self.buffer = ExperienceReplay(params["experience_size"], env.action_size, params["bit_depth"], False,
+                                       env.observation_size, self.device)
+        self.load(params)
+
+    # ---------------------------------------------------------------------------------------- checkpoints
+    def load(self, params: Dict[str, Any]) -> None:
+        """src/planet.py:103-114: load the reference's checkpoint dict (weights only, no code execution)."""
+        path = params.get("models", "")
+        if path and os.path.exists(path):
+            d = torch.load(path, map_location="cpu", weights_only=True)
+            for key in ("transition_model", "observation_model", "reward_model", "encoder"):
+                getattr(self, key).load_state_dict(d[key])
+
+    def eval(self) -> None:      # no dropout / batch-norm anywhere on the path
+        pass
+
+    def train(self) -> None:
+        pass
+
+    # ---------------------------------------------------------------------------------------- replay
+    def randomly_initialize_replay_buffer(self) -> Tuple[int, int]:
+        """src/planet.py:136-159."""
+        total_steps, s = 0, 0
+        while total_steps < self.seed_steps:
+            done, t = False, 0
+            observation = self.env.reset()
+            while not done:
+                action = self.env.sample_random_action()
+                next_observation, reward, done = self.env.step(action)
+                self.buffer.append(observation, action, reward, done)
+                observation = next_observation
+                t += 1
+            s += 1
+            total_steps += t * self.action_repeat
+        self.env.close()
+        return total_steps, s
+
+    # ---------------------------------------------------------------------------------------- training
+    def train_step(self) -> Dict[str, float]:
+        """src/dreamer.py:253-393.  Returns the reference's log dict."""
+        obs, actions, rewards, nonterminals = self.buffer.sample(self.batch_size, self.seq_len)
+        logs = self.engine.train_step({"observations": obs, "actions": actions, "rewards": rewards,
+                                       "nonterminals": nonterminals})
+        return {k: v for k, v in logs.items() if not k.startswith("grad_norm")}
+
+    def update_critic(self) -> None:
+        self.engine.update_critic()
+
+    # ---------------------------------------------------------------------------------------- acting / imagination
+    @torch.no_grad()
+    def imagine_ahead(self, prev_state: Tensor, prev_belief: Tensor, _noise: Optional[Dict[str, Tensor]] = None):
+        """src/dreamer.py:179-237: (seq,batch,S), (seq,batch,Be) -> beliefs (H-1,N,Be), prior_states (H-1,N,S),
+        (prior_means, prior_stds), action_entropy (H-1,N)."""
+        e, d = self.engine, self.dims
+        N = prev_state.shape[0] * prev_state.shape[1]
+        start = torch.cat([prev_belief.reshape(N, d.Be), prev_state.reshape(N, d.S)], dim=1).contiguous().float()
+        Hm = self.planning_horizon - 1
+        noise = _noise or {"action": torch.randn(Hm, N, d.A, device=e.dev),
+                           "entropy": torch.randn(Hm, d.n_entropy, N, d.A, device=e.dev),
+                           "img_prior": torch.randn(Hm, N, d.S, device=e.dev)}
+        ifeat, ent, _ = e.imagine(start, N, Hm, noise, save=False, tag="api_")
+        f = ifeat.view(Hm, N, d.Be + d.S)
+        pm = e._buf["api_iprior_mean"].view(Hm, N, d.S).clone()
+        ps = e._buf["api_iprior_std"].view(Hm, N, d.S).clone()
+        return f[..., :d.Be].clone(), f[..., d.Be:].clone(), (pm, ps), ent.view(Hm, N).clone()
+
+    @torch.no_grad()
+    def get_action(self, belief: Tensor, state: Tensor, deterministic: bool = False,
+                   _noise: Optional[Dict[str, Tensor]] = None) -> Tuple[Tensor, Tensor]:
+        """src/dreamer.py:429-444: tanh-Normal sample and its 100-sample entropy estimate."""
+        if deterministic:
+            raise NotImplementedError("deterministic=True (SampleDist.mode) is never used by the reference loop")
+        e, d = self.engine, self.dims
+        N = belief.shape[0]
+        start = torch.cat([belief, state], dim=1).contiguous().float()
+        noise = _noise or {"action": torch.randn(1, N, d.A, device=e.dev),
+                           "entropy": torch.randn(1, d.n_entropy, N, d.A, device=e.dev),
+                           "img_prior": torch.randn(1, N, d.S, device=e.dev)}
+        _, ent, act = e.imagine(start, N, 1, noise, save=False, tag="act_")   # one step: actor + sample (+ unused prior)
+        return act.view(N, d.A).clone(), ent.view(N).clone()
+
+    @torch.no_grad()
+    def update_belief_and_act(self, env, belief, posterior_state, action, observation, explore=False):
+        """src/planet.py:370-403."""
+        embedding = self.encoder(observation.to(self.device)).unsqueeze(dim=0)
+        belief, _, _, posterior_state, _ = self.transition_model(posterior_state, action.unsqueeze(dim=0), belief,
+                                                                 embedding)
+        belief, posterior_state = belief.squeeze(dim=0), posterior_state.squeeze(dim=0)
+        action, _ = self.get_action(belief, posterior_state)
+        if explore:
+            action = torch.clamp(action + self.action_noise * torch.randn_like(action), -1, 1)
+        batched = hasattr(env, "n") and hasattr(env, "envs")          # EnvBatcher (src/env.py:343)
+        next_observation, reward, done = env.step(action.cpu() if batched else action[0].cpu())
+        return belief, posterior_state, action, next_observation, reward, done
+
+
+def lambda_return(imged_reward: Tensor, value_pred: Tensor, bootstrap: Tensor, discount: float = 0.99,
+                  lambda_: float = 0.95) -> Tensor:
+    """src/dreamer.py:447-471 on the GPU (bd_lambda_return_forward).  The kernel takes the bootstrap from the
+    last value row, as the only call site does (``bootstrap=value_pred[-1]``, src/dreamer.py:332)."""
+    if not torch.equal(bootstrap, value_pred[-1]):
+        raise NotImplementedError("bootstrap must be value_pred[-1] (the reference's only use)")
+    Hm = imged_reward.shape[0]
+    N = imged_reward[0].numel()
+    r, v = imged_reward.contiguous().float(), value_pred.contiguous().float()
+    out = torch.empty_like(r)
+    cabi.check(cabi.lib.bd_lambda_return_forward(r.data_ptr(), v.data_ptr(), Hm, N, discount, lambda_, out.data_ptr(),
+                                                 cabi.stream()))
+    return out
+
+
+# -------------------------------------------------------------------------------------------------
+# PyTorch-default initialisation of the reference's modules (shapes: src/models.py, src/utils.py:368-404)
+def _ref_init_dense(i: int, h: int, o: int) -> torch.nn.Module:
+    from torch import nn
+    layers, k = [], i
+    for _ in range(4):
+        layers += [nn.Linear(k, h), nn.ELU()]
+        k = h
+    layers += [nn.Linear(k, o), nn.Identity()]
+    m = nn.Module()
+    m.model = nn.Sequential(*layers)
+    return m
+
+
+def _ref_init_transition(d: Dims) -> torch.nn.Module:
+    from torch import nn
+    from .models import GaussianBeliefHolder
+    m = nn.Module()
+    m.rnn = nn.GRUCell(d.Be, d.Be)
+    m.fc_embed_state_action = nn.Sequential(nn.Linear(d.S + d.A, d.Be), nn.ELU())
+    m.belief_prior = GaussianBeliefHolder(d.Be, d.Hd, d.S, 0.1)
+    m.belief_posterior = GaussianBeliefHolder(d.Be + d.E, d.Hd, d.S, 0.1)
+    return m

@@ -294,7 +294,8 @@ class DreamerEngine:
         self.mlp_forward(M, obs2d, d.O, d.O, layers, acts + [emb, None], pre, d.Hd)
         return emb, pre
 
-    def observe(self, actions, nonterm, pre_emb, eps_post, init_belief, init_state, T: int, B: int, save: bool = True):
+    def observe(self, actions, nonterm, pre_emb, eps_post, init_belief, init_state, T: int, B: int, save: bool = True,
+                tag: str = ""):
         """TransitionModel.forward recurrence (posterior path).  Returns feat [T*B x (Be+S)], post_mean, post_std."""
         d, pk = self.d, self.pk
         tm = lambda n: self.W("transition_model", n)
@@ -310,8 +311,8 @@ class DreamerEngine:
         a.init_belief, a.init_state, a.actions = ptr(init_belief), ptr(init_state), ptr(actions)
         a.nonterm, a.pre_emb, a.eps_post = ptr(nonterm), ptr(pre_emb), ptr(eps_post)
         a.min_std = self.hp["min_std_dev"]
-        feat = self.buf("feat", M, d.Be + d.S)
-        qm, qs = self.buf("post_mean", M, d.S), self.buf("post_std", M, d.S)
+        feat = self.buf(tag + "feat", M, d.Be + d.S)
+        qm, qs = self.buf(tag + "post_mean", M, d.S), self.buf(tag + "post_std", M, d.S)
         a.feat, a.post_mean, a.post_std = ptr(feat), ptr(qm), ptr(qs)
         if save:
             a.sv_s, a.sv_x = ptr(self.buf("sv_s", M, d.S)), ptr(self.buf("sv_x", M, d.Be))
@@ -320,15 +321,16 @@ class DreamerEngine:
             cabi.check(lib.bd_observe_forward(C.byref(a), cabi.stream()))
         return feat, qm, qs
 
-    def prior_head(self, feat, M: int, eps):
+    def prior_head(self, feat, M: int, eps, tag: str = ""):
         """belief_prior on all beliefs at once (src/models.py:256): returns state, mean, std [M x S]."""
         d = self.d
         tm = lambda n: self.W("transition_model", n)
         layers = [("p1", tm("belief_prior.model.0.bias"), d.Hd, d.Be, cabi.ACT_ELU),
                   ("p2", tm("belief_prior.model.2.bias"), 2 * d.S, d.Hd, cabi.ACT_NONE)]
-        hid, out = self.buf("p_hid", M, d.Hd), self.buf("p_out", M, 2 * d.S)
+        hid, out = self.buf(tag + "p_hid", M, d.Hd), self.buf(tag + "p_out", M, 2 * d.S)
         self.mlp_forward(M, feat, d.Be + d.S, d.Be, layers, [hid, None], out, 2 * d.S)
-        pm, ps, pst = self.buf("prior_mean", M, d.S), self.buf("prior_std", M, d.S), self.buf("prior_state", M, d.S)
+        pm, ps, pst = (self.buf(tag + "prior_mean", M, d.S), self.buf(tag + "prior_std", M, d.S),
+                       self.buf(tag + "prior_state", M, d.S))
         cabi.check(lib.bd_gauss_head_forward(ptr(out), ptr(eps), M, d.S, self.hp["min_std_dev"], ptr(pm), ptr(ps),
                                              ptr(pst), cabi.stream()))
         return pst, pm, ps
@@ -341,7 +343,7 @@ class DreamerEngine:
         self.mlp_forward(M, x, ldx, ldx, layers, acts + [None], out, out_width)
         return out, acts, layers
 
-    def imagine(self, start_feat, N: int, Hm: int, noise, save: bool = True):
+    def imagine(self, start_feat, N: int, Hm: int, noise, save: bool = True, tag: str = ""):
         d, pk = self.d, self.pk
         tm = lambda n: self.W("transition_model", n)
         ac = lambda n: self.W("actor", n)
@@ -364,10 +366,11 @@ class DreamerEngine:
         a.eps_action, a.eps_entropy, a.eps_prior = ptr(noise["action"]), ptr(noise["entropy"]), ptr(noise["img_prior"])
         a.min_std, a.act_raw_init_std = self.hp["min_std_dev"], ACT_RAW_INIT_STD
         a.act_min_std, a.act_mean_scale = ACT_MIN_STD, ACT_MEAN_SCALE
-        ifeat = self.buf("ifeat", Mi, d.Be + d.S)
+        ifeat = self.buf(tag + "ifeat", Mi, d.Be + d.S)
         a.feat = ptr(ifeat)
-        a.prior_mean, a.prior_std = ptr(self.buf("iprior_mean", Mi, d.S)), ptr(self.buf("iprior_std", Mi, d.S))
-        ent, act = self.buf("entropy", Mi), self.buf("action", Mi, d.A)
+        a.prior_mean = ptr(self.buf(tag + "iprior_mean", Mi, d.S))
+        a.prior_std = ptr(self.buf(tag + "iprior_std", Mi, d.S))
+        ent, act = self.buf(tag + "entropy", Mi), self.buf(tag + "action", Mi, d.A)
         a.entropy, a.action = ptr(ent), ptr(act)
         if save:
             a.sv_actor = ptr(self.buf("sv_actor", DENSE_LAYERS, Mi, d.Hd))

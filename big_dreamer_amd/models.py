@@ -1,0 +1,150 @@
+"""Reference-compatible model classes (src/models.py) on top of the HIP engine.
+
+The classes keep the reference's constructor signatures, attribute names and ``state_dict`` keys/shapes
+(SURVEY.md section 8b), so ``models=`` checkpoints of the reference load unchanged.  Their parameters are
+*views into the engine's flat fp32 buffers* (one per optimiser), so the HIP kernels, the fused clip+Adam and
+the RCCL all-reduce all see the same memory; after ``load_state_dict`` the packed kernel copies are refreshed.
+
+``forward`` runs the HIP kernels (inference-style: no autograd graph; training goes through
+``Dreamer.train_step`` whose backward schedule is explicit).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from .engine import DreamerEngine
+from .synth import DENSE_LAYERS
+
+
+def _alias(module: nn.Module, eng: DreamerEngine, mod: str, prefix: str = "") -> None:
+    """Point every parameter of `module` at the engine's storage for (mod, prefix+name)."""
+    for name, p in module.named_parameters():
+        view = eng.W(mod, prefix + name)
+        assert tuple(view.shape) == tuple(p.shape), (mod, prefix + name, view.shape, p.shape)
+        p.data = view
+        p.requires_grad_(False)     # gradients live in the engine's flat gradient buffers
+
+
+class _EngineBacked(nn.Module):
+    """Base: re-pack the kernel weight copies whenever a state dict is loaded."""
+
+    def _bind(self, eng: DreamerEngine, mod: str, group: str) -> None:
+        object.__setattr__(self, "_eng", eng)
+        self._mod, self._group = mod, group
+        _alias(self, eng, mod)
+        self.register_load_state_dict_post_hook(lambda m, keys: m._eng.pack(m._group))
+
+
+class DenseModel(_EngineBacked):
+    """src/models.py:365-408: build_mlp(input, hidden, output, n_layers=4) -> ``model.{0,2,4,6,8}``."""
+
+    def __init__(self, input_size: int, hidden_size: int, output_size: int = 1, activation: str = "ELU",
+                 n_layers: int = DENSE_LAYERS, distribution: str = "normal", *, engine: DreamerEngine, module: str,
+                 prefix: str):
+        super().__init__()
+        assert activation == "ELU" and n_layers == DENSE_LAYERS, "the HIP path implements the reference defaults"
+        layers, i = [], input_size
+        for _ in range(n_layers):
+            layers += [nn.Linear(i, hidden_size), nn.ELU()]
+            i = hidden_size
+        layers += [nn.Linear(i, output_size), nn.Identity()]
+        self.model = nn.Sequential(*layers)
+        self.distribution = distribution
+        self._in, self._out, self._prefix = input_size, output_size, prefix
+        group = {"critic": "critic", "critic_target": "critic_target", "actor": "actor"}.get(module, "model")
+        self._bind(engine, module, group)
+
+    def forward(self, *args: Tensor) -> Tensor:
+        x = torch.cat(args, dim=-1) if len(args) == 2 else args[0]
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, self._in).contiguous().float()
+        out, _, _ = self._eng.dense_forward(self._mod, self._prefix, "api_" + self._mod, x2, self._in, x2.shape[0],
+                                            self._out)
+        return out.clone().view(*lead, self._out)
+
+
+class GaussianBeliefHolder(nn.Module):
+    """Parameter container with the reference's names (``model.0``, ``model.2``; src/models.py:44-73)."""
+
+    def __init__(self, input_size: int, hidden_size: int, state_size: int, min_std_dev: float):
+        super().__init__()
+        self.min_std_dev = min_std_dev
+        self.model = nn.Sequential(nn.Linear(input_size, hidden_size), nn.ELU(), nn.Linear(hidden_size, 2 * state_size),
+                                   nn.Identity())
+
+
+class TransitionModel(_EngineBacked):
+    """src/models.py:120-299 (Gaussian latents).  ``forward`` returns the reference's 5-tuple."""
+
+    def __init__(self, belief_size: int, state_size: int, action_size: int, hidden_size: int, embedding_size: int,
+                 activation: Optional[str] = "ELU", min_std_dev: float = 0.1,
+                 latent_distribution: Optional[str] = "Gaussian", discrete_latent_dimensions: Optional[int] = 32,
+                 discrete_latent_classes: Optional[int] = 32, *, engine: DreamerEngine):
+        super().__init__()
+        if latent_distribution != "Gaussian":
+            # the reference's Categorical path crashes at HEAD (src/models.py:284)
+            raise NotImplementedError("latent_distribution='Categorical' is not implemented (parity unpinned)")
+        assert activation == "ELU"
+        self.min_std_dev = min_std_dev
+        self.latent_distribution = latent_distribution
+        self.rnn = nn.GRUCell(belief_size, belief_size)
+        self.fc_embed_state_action = nn.Sequential(nn.Linear(state_size + action_size, belief_size), nn.ELU())
+        self.belief_prior = GaussianBeliefHolder(belief_size, hidden_size, state_size, min_std_dev)
+        self.belief_posterior = GaussianBeliefHolder(belief_size + embedding_size, hidden_size, state_size, min_std_dev)
+        self._dims = (belief_size, state_size, action_size, hidden_size, embedding_size)
+        self._bind(engine, "transition_model", "model")
+
+    @torch.no_grad()
+    def forward(self, init_state: Tensor, actions: Tensor, init_belief: Tensor, embeddings: Optional[Tensor] = None,
+                nonterminals: Optional[Tensor] = None, _noise: Optional[Tuple[Tensor, Tensor]] = None):
+        """init_state (B,S), actions (T,B,A), init_belief (B,Be), embeddings (T,B,E), nonterminals (T,B,1) ->
+        beliefs (T,B,Be), prior_states, (prior_means, prior_stds), posterior_states, (post_means, post_stds)."""
+        if embeddings is None:
+            raise NotImplementedError("prior-only rollout (embeddings=None) is only used by the PlaNet MPC planner, "
+                                      "which is outside this build's hot path (DESIGN.md, scope)")
+        eng = self._eng
+        Be, S, A, Hd, E = self._dims
+        T, B = actions.shape[0], actions.shape[1]
+        M = T * B
+        f = lambda t: t.contiguous().float()
+        pre = eng.buf("api_pre_emb", M, Hd)
+        eng.mlp_forward(M, f(embeddings).view(M, E), E, E, [("q1e", None, Hd, E, 0)], None, pre, Hd)
+        if _noise is None:      # (prior eps, posterior eps); the parity tests inject the oracle's draws
+            eps_p, eps_q = torch.randn(T, B, S, device=eng.dev), torch.randn(T, B, S, device=eng.dev)
+        else:
+            eps_p, eps_q = f(_noise[0]), f(_noise[1])
+        feat, qm, qs = eng.observe(f(actions), None if nonterminals is None else f(nonterminals), pre, eps_q,
+                                   f(init_belief), f(init_state), T, B, save=False, tag="api_")
+        pst, pm, ps = eng.prior_head(feat, M, eps_p, tag="api_")
+        feat = feat.view(T, B, Be + S)
+        v = lambda t: t.clone().view(T, B, S)
+        return (feat[..., :Be].clone(), v(pst), (v(pm), v(ps)), feat[..., Be:].clone(), (v(qm), v(qs)))
+
+
+class ActorModel(_EngineBacked):
+    """src/models.py:466-524 (Gaussian action distribution).  ``forward`` returns (action_mean, action_std)."""
+
+    def __init__(self, belief_size: int, state_size: int, hidden_size: int, action_size: int,
+                 activation_function: str = "ELU", action_distribution: str = "Gaussian", min_std: float = 1e-4,
+                 init_std: float = 5, mean_scale: float = 5, n_layers: int = DENSE_LAYERS, *, engine: DreamerEngine):
+        super().__init__()
+        if action_distribution != "Gaussian":
+            raise NotImplementedError("only the Gaussian action distribution is on the hot path")
+        layers, i = [], belief_size + state_size
+        for _ in range(n_layers):
+            layers += [nn.Linear(i, hidden_size), nn.ELU()]
+            i = hidden_size
+        layers += [nn.Linear(i, 2 * action_size), nn.Identity()]
+        self.model = nn.Sequential(*layers)
+        self._min_std, self._init_std, self._mean_scale = min_std, init_std, mean_scale
+        self.raw_init_std = torch.log(torch.exp(torch.tensor(float(init_std))) - 1)
+        self.action_distribution = action_distribution
+        self._bind(engine, "actor", "actor")
+
+
+def encoder_for(engine: DreamerEngine, observation_size: int, hidden_size: int, embedding_size: int) -> DenseModel:
+    """State-observation encoder (src/planet.py:195-200)."""
+    return DenseModel(observation_size, hidden_size, embedding_size, engine=engine, module="encoder", prefix="enc")

@@ -55,3 +55,15 @@ def test_replay_sample_indices_match_reference():
         np.testing.assert_array_equal(buf.rewards[vec].reshape(7, 6), g[f"{case}.rewards"])
         np.testing.assert_array_equal(buf.nonterminals[vec].reshape(7, 6, 1), g[f"{case}.nonterminals"])
         assert not any(buf.idx in row[1:] for row in idxs)
+
+
+def test_config_overrides_like_hydra():
+    """key=value / group.key=value overrides on the reference's config keys (src/conf/config.yaml)."""
+    from big_dreamer_amd.config import load_config
+    cfg = load_config(["batch_size=7", "ActorCritic.entropy_weight=1e-4", "env=HumanoidStandup-v2", "models=''"])
+    assert cfg["batch_size"] == 7 and cfg["ActorCritic"]["entropy_weight"] == 1e-4
+    assert cfg["env"] == "HumanoidStandup-v2" and cfg["models"] in ("", None)
+    assert cfg["model_learning_rate"] == 2e-4 and cfg["ActorCritic"]["actor_learning_rate"] == 4e-5
+    assert cfg["planning_horizon"] == 15 and cfg["kl_balance"] == 0.8 and cfg["free_nats"] == 3.0
+    with pytest.raises(KeyError):
+        load_config(["not_a_key=1"])

@@ -1,0 +1,31 @@
+"""Diagnostic: phase timeline of one imagination step from s_memtime stamps (needs a -DBD_STAMPS build:
+make -C big_dreamer_amd/csrc CXXFLAGS_EXTRA=-DBD_STAMPS LIB=../libbd_stamps.so; run with BD_LIB=...)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from big_dreamer_amd import _cabi, synth  # noqa: E402
+from big_dreamer_amd.engine import DreamerEngine  # noqa: E402
+
+d = synth.CONFIG2
+eng = DreamerEngine(d, None, "cuda", params=synth.make_params(d, 0))
+batch = {k: torch.as_tensor(v).cuda() for k, v in synth.make_batch(d, 0).items()}
+for _ in range(3):
+    eng.train_step(batch, None)
+torch.cuda.synchronize()
+out = (ctypes.c_ulonglong * 64)()
+fn = _cabi.lib.bd_debug_stamps
+fn.restype = ctypes.c_int
+assert fn(out) == 0
+st = np.array(out[:15], dtype=np.int64)
+names = ["actor L0", "barrier", "actor L1-3 (+3 barriers)", "actor out+sample", "barrier", "entropy (+2 barriers)",
+         "embed", "barrier", "GRU", "barrier", "prior hidden", "barrier", "prior out+sample", "barrier"]
+tot = st[14] - st[0]
+print(f"one imagination step of workgroup {os.environ.get('BD_STAMP_WG', 0)}: {tot} ticks (s_memtime @100MHz => {tot/100:.1f} us)")
+for i, n in enumerate(names):
+    dt = st[i + 1] - st[i]
+    print(f"  {n:28s} {dt:8d} ticks  {100.0 * dt / tot:5.1f} %")
