@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import _cabi as cabi
+from .parallel import DataParallel
 from .synth import DENSE_LAYERS, MODEL_MODULES, Dims, param_shapes
 
 lib = cabi.lib
@@ -75,6 +76,8 @@ class DreamerEngine:
         assert self.dev.type == "cuda", "the HIP path needs a GPU (there is no CPU fallback)"
         self.world_size = world_size
         self.pg = process_group
+        self.dp = DataParallel(world_size, torch.distributed.get_rank(process_group) if world_size > 1 else 0,
+                               process_group)
         d = dims
         shapes = param_shapes(d)
         self.groups = {
@@ -262,8 +265,7 @@ class DreamerEngine:
                        self.G(mod, f"model.{2 * l}.weight"), sizes[l], self.G(mod, f"model.{2 * l}.bias"))
 
     def _allreduce(self, t: torch.Tensor) -> None:
-        if self.world_size > 1:
-            torch.distributed.all_reduce(t, group=self.pg)
+        self.dp.allreduce_sum_(t)
 
     def optimizer_step(self, group: str, slot: int, lr: float) -> None:
         g = self.groups[group]
@@ -421,7 +423,7 @@ class DreamerEngine:
             om_out, om_acts, om_layers = self.dense_forward("observation_model", "obs", "om", feat, F, N, d.O)
             rw_out, rw_acts, rw_layers = self.dense_forward("reward_model", "rew", "rw", feat, F, N, 1)
 
-        inv_rows = 1.0 / (N * W)
+        inv_rows = self.dp.mean_grad_scale(N)
         d_om, d_rw = self.buf("d_om_out", N, d.O), self.buf("d_rw_out", N, 1)
         cabi.check(lib.bd_normal_nll(ptr(om_out), d.O, ptr(obs_t), d.O, N, d.O, inv_rows, ptr(d_om), d.O, sc, SLOT_OBS, ws, st))
         cabi.check(lib.bd_normal_nll(ptr(rw_out), 1, ptr(rewards[:-1]), 1, N, 1, inv_rows, ptr(d_rw), 1, sc, SLOT_REW, ws, st))
@@ -511,7 +513,7 @@ class DreamerEngine:
         cabi.check(lib.bd_lambda_return_forward(ptr(r_out), ptr(v_out), Hm, N, hp["discount"], hp["disclam"], ptr(returns), st))
         cabi.check(lib.bd_sum(ptr(returns), Mi, sc, SLOT_RET, ws, st))
         cabi.check(lib.bd_sum(ptr(ent), Mi, sc, SLOT_ENT, ws, st))
-        inv_mi = 1.0 / (Mi * W)
+        inv_mi = self.dp.mean_grad_scale(Mi)
         d_r, d_v = self.buf("d_ir_out", Mi), self.buf("d_iv_out", Mi)
         cabi.check(lib.bd_lambda_return_backward(None, -inv_mi, Hm, N, hp["discount"], hp["disclam"], ptr(d_r), ptr(d_v), st))
         difeat = self.buf("difeat", Mi, F)
