@@ -226,13 +226,70 @@ __device__ __forceinline__ void linear_blocks(const Seg (&seg)[NSEG], const floa
         for (int rt = 0; rt < RT; ++rt) epi(rt, nb0 + i * kWaves, acc[i][rt]);
 }
 
+// ---- split-K over waves for narrow outputs ----------------------------------------------------------------
+// When a layer has at most two (column block, row tile) pairs (N <= 32: the mean/std heads, the N=1 heads of the
+// reward/value chains, the d/d(state|action) of the embed layer) the column-block decomposition leaves all but
+// one or two waves idle while those walk every K block in sequence: ~one L2 round trip per block pair.  Here
+// every wave takes the K blocks kb = wave, wave+kWaves, ... of ALL pairs, partial accumulators meet in an LDS
+// scratch ([kWaves][pairs][64 lanes] float4) and the first `pairs` waves sum them in fixed order (deterministic)
+// and run the epilogue.  Costs one extra barrier, removes ~Kb/kWaves round trips from the step's critical path.
+constexpr int kSplitPairs = 2;
+constexpr int kSplitScratchFloats = kWaves * kSplitPairs * 2 * kFragFloats;   // dual form needs 2 outputs per pair
+
+template <int RT, int NSEG, class Epi>
+__device__ __forceinline__ void tile_linear_splitk(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
+                                                   float* __restrict__ scratch, Epi&& epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Nb = (N + 15) >> 4;
+    const int P = Nb * RT;                      // <= kSplitPairs (checked by the caller)
+    floatx4 acc[kSplitPairs];
+#pragma unroll
+    for (int p = 0; p < kSplitPairs; ++p) acc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        const int Kb = seg[s].Kb;
+        const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(seg[s].X) + lane;
+        const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(seg[s].W) + lane;
+        for (int kb = wave; kb < Kb; kb += kWaves) {
+#pragma unroll
+            for (int p = 0; p < kSplitPairs; ++p) {
+                if (p < P) {
+                    const int nb = p / RT, rt = p - nb * RT;
+                    const floatx4 a4 = X4[(rt * Kb + kb) * 64];
+                    const floatx4 b4 = W4[((size_t)nb * Kb + kb) * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[p] = mfma16(a4[j], b4[j], acc[p]);
+                }
+            }
+        }
+    }
+    floatx4* __restrict__ S4 = reinterpret_cast<floatx4*>(scratch);
+#pragma unroll
+    for (int p = 0; p < kSplitPairs; ++p)
+        if (p < P) S4[(wave * kSplitPairs + p) * 64 + lane] = acc[p];
+    lds_barrier();
+    if (wave < P) {
+        const int nb = wave / RT, rt = wave - nb * RT;
+        const int col = nb * 16 + (lane & 15);
+        const float b = (bias != nullptr && col < N) ? bias[col] : 0.f;
+        floatx4 r = floatx4{b, b, b, b};
+        for (int w = 0; w < kWaves; ++w) r += S4[(w * kSplitPairs + wave) * 64 + lane];
+        epi(rt, nb, r);
+    }
+}
+
 // Each wave owns column blocks nb = wave, wave+kWaves, ...; two are kept in flight where two exist (independent
 // MFMA chains: 16x16x4 f32 issues every 32 cycles but a dependent one needs 40), the odd last one runs alone.
 // epi(rt, nb, acc): lane holds out[row = 16*rt + 4*(lane>>4) + r][col = nb*16 + (lane&15)], r = 0..3.
 template <int RT, int NSEG, class Epi>
-__device__ __forceinline__ void tile_linear_g(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Epi&& epi) {
+__device__ __forceinline__ void tile_linear_g(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Epi&& epi,
+                                              float* __restrict__ scratch = nullptr) {
     const int wave = threadIdx.x >> 6;
     const int Nb = (N + 15) >> 4;
+    if (scratch != nullptr && Nb * RT <= kSplitPairs) {   // workgroup-uniform
+        tile_linear_splitk<RT, NSEG>(seg, bias, N, scratch, epi);
+        return;
+    }
     constexpr int D = 2;
     for (int nb0 = wave; nb0 < Nb; nb0 += 2 * kWaves) {
         if (nb0 + kWaves < Nb) linear_blocks<NSEG, RT, 2, D>(seg, bias, N, nb0, epi);
@@ -243,15 +300,16 @@ __device__ __forceinline__ void tile_linear_g(const Seg (&seg)[NSEG], const floa
 // single-segment convenience forms
 template <int RT, int NI_UNUSED, class Epi>
 __device__ __forceinline__ void tile_linear(const float* __restrict__ X, int Kb, const float* __restrict__ Wp,
-                                            const float* __restrict__ bias, int N, Epi&& epi) {
+                                            const float* __restrict__ bias, int N, Epi&& epi,
+                                            float* __restrict__ scratch = nullptr) {
     const Seg seg[1] = {{X, Wp, Kb}};
-    tile_linear_g<RT, 1>(seg, bias, N, epi);
+    tile_linear_g<RT, 1>(seg, bias, N, epi, scratch);
 }
 
 template <int NI_UNUSED, int NSEG, class Epi>
 __device__ __forceinline__ void tile_linear_seg(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
-                                                Epi&& epi) {
-    tile_linear_g<1, NSEG>(seg, bias, N, [&](int, int nb, floatx4 acc) { epi(nb, acc); });
+                                                Epi&& epi, float* __restrict__ scratch = nullptr) {
+    tile_linear_g<1, NSEG>(seg, bias, N, [&](int, int nb, floatx4 acc) { epi(nb, acc); }, scratch);
 }
 
 // Two outputs sharing one column index (mean / raw-std rows of a Gaussian head): out0 = sum_s X_s W0_s^T + bias0,
@@ -270,9 +328,56 @@ struct DualFrag {
 
 template <int NSEG, class Epi>
 __device__ __forceinline__ void tile_linear_dual(const Seg2 (&seg)[NSEG], const float* __restrict__ bias0,
-                                                 const float* __restrict__ bias1, int N, Epi&& epi) {
+                                                 const float* __restrict__ bias1, int N, Epi&& epi,
+                                                 float* __restrict__ scratch = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Nb = (N + 15) >> 4;
+    if (scratch != nullptr && Nb <= kSplitPairs) {   // split-K over waves (see tile_linear_splitk); both W0, W1 given
+        floatx4 a0[kSplitPairs], a1[kSplitPairs];
+#pragma unroll
+        for (int p = 0; p < kSplitPairs; ++p) a0[p] = a1[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) {
+            const int Kb = seg[s].Kb;
+            const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(seg[s].X) + lane;
+            const floatx4* __restrict__ W0 = reinterpret_cast<const floatx4*>(seg[s].W0) + lane;
+            const floatx4* __restrict__ W1 = reinterpret_cast<const floatx4*>(seg[s].W1) + lane;
+            for (int kb = wave; kb < Kb; kb += kWaves) {
+                const floatx4 x4 = X4[kb * 64];
+#pragma unroll
+                for (int p = 0; p < kSplitPairs; ++p) {
+                    if (p < Nb) {
+                        const floatx4 p4 = W0[((size_t)p * Kb + kb) * 64], q4 = W1[((size_t)p * Kb + kb) * 64];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            a0[p] = mfma16(x4[j], p4[j], a0[p]);
+                            a1[p] = mfma16(x4[j], q4[j], a1[p]);
+                        }
+                    }
+                }
+            }
+        }
+        floatx4* __restrict__ S4 = reinterpret_cast<floatx4*>(scratch);
+#pragma unroll
+        for (int p = 0; p < kSplitPairs; ++p)
+            if (p < Nb) {
+                S4[((wave * kSplitPairs + p) * 2 + 0) * 64 + lane] = a0[p];
+                S4[((wave * kSplitPairs + p) * 2 + 1) * 64 + lane] = a1[p];
+            }
+        lds_barrier();
+        if (wave < Nb) {
+            const int col = wave * 16 + (lane & 15);
+            const float b0 = (bias0 != nullptr && col < N) ? bias0[col] : 0.f;
+            const float b1 = (bias1 != nullptr && col < N) ? bias1[col] : 0.f;
+            floatx4 r0 = floatx4{b0, b0, b0, b0}, r1 = floatx4{b1, b1, b1, b1};
+            for (int w = 0; w < kWaves; ++w) {
+                r0 += S4[((w * kSplitPairs + wave) * 2 + 0) * 64 + lane];
+                r1 += S4[((w * kSplitPairs + wave) * 2 + 1) * 64 + lane];
+            }
+            epi(wave, r0, r1);
+        }
+        return;
+    }
     for (int nb = wave; nb < Nb; nb += kWaves) {
         const int col = nb * 16 + (lane & 15);
         const float b0 = (bias0 != nullptr && col < N) ? bias0[col] : 0.f;

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
     float* std_s = mean_s + 16 * A;               // [16][A]
     float* lp_rj = std_s + 16 * A;                // [16][A]
     float* part = lp_rj + 16 * A;                 // [kWaves][16][A][3]
+    float* scratch = part + kWaves * 16 * A * 3;  // split-K partials (kSplitScratchFloats); 16-byte aligned: see host
 
     load_tile_concat<1>(h_cur, d.Kb_h, row0, a.N, a.start_feat, F, a.Be, nullptr, 0, 0);
     load_tile_concat<1>(sf, d.Kb_s, row0, a.N, a.start_feat + a.Be, F, a.S, nullptr, 0, 0);
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                     }
                     af[acc_frag_off(nb, lane, r)] = act;
                 }
-            });
+            }, scratch);
         }
         BD_STAMP(4);
         lds_barrier();
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                     }
                     sf[acc_frag_off(nb, lane, r)] = st;
                 }
-            });
+            }, scratch);
         }
         BD_STAMP(13);
         lds_barrier();
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
     float* dAm = dRaw + ns;       // Kb_a
     float* dAr = dAm + na;
     float* ds_plain = dAr + na;   // [16][S]
+    float* scratch = ds_plain + 16 * a.S;   // split-K partials (kSplitScratchFloats)
 
     for (int i = threadIdx.x; i < nh; i += blockDim.x) dhc[i] = 0.f;
     for (int i = threadIdx.x; i < 16 * a.S; i += blockDim.x) ds_plain[i] = 0.f;
@@ -412,7 +414,8 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
                 const int row = 4 * (lane >> 4) + r;
                 if (col < a.S) ds_plain[row * a.S + col] = (row0 + row < a.N) ? acc[r] : 0.f;
             }
-        });
+        }, scratch);
+        lds_barrier();   // the split-K scratch is reused by the next contraction
         tile_linear<1, kNI>(dE, d.Kb_h, a.wt_embed_a, nullptr, A, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
                 dAm[acc_frag_off(nb, lane, r)] = gm;
                 dAr[acc_frag_off(nb, lane, r)] = gr;
             }
-        });
+        }, scratch);
         lds_barrier();
         // ---- 6: actor MLP backward (input detached: no gradient below layer 0) ----
         {
@@ -482,8 +485,9 @@ int bd_imagine_forward(const bd_imagine_fwd_args* a, void* stream) {
     BD_REQUIRE(a->start_feat && a->eps_action && a->eps_entropy && a->eps_prior, "bd_imagine_forward: missing inputs");
     BD_REQUIRE(a->feat && a->prior_std && a->entropy && a->action, "bd_imagine_forward: missing outputs");
     const ImgDims d(a->Be, a->S, a->A, a->Hd);
-    const size_t lds = ((size_t)(3 * d.Kb_h + 2 * d.Kb_hd + d.Kb_s + d.Kb_a) * kFragFloats + (size_t)(3 * 16 + kWaves * 16 * 3) * a->A) *
-                       sizeof(float);
+    // (3*16 + kWaves*16*3)*A floats of small arrays: a multiple of 16 floats, so the scratch stays 16-byte aligned
+    const size_t lds = ((size_t)(3 * d.Kb_h + 2 * d.Kb_hd + d.Kb_s + d.Kb_a) * kFragFloats +
+                        (size_t)(3 * 16 + kWaves * 16 * 3) * a->A + kSplitScratchFloats) * sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_imagine_forward: needs %zu B of LDS", lds);
     if (lds > 64 * 1024 && allow_big_lds(imagine_fwd_kernel)) return -1;
     hipLaunchKernelGGL(imagine_fwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);
@@ -502,7 +506,8 @@ int bd_imagine_backward(const bd_imagine_bwd_args* a, void* stream) {
                "bd_imagine_backward: missing forward tensors");
     BD_REQUIRE(a->d_actor_pre && a->d_actor_out, "bd_imagine_backward: missing outputs");
     const ImgDims d(a->Be, a->S, a->A, a->Hd);
-    const size_t lds = ((size_t)(6 * d.Kb_h + 3 * d.Kb_hd + 2 * d.Kb_s + 2 * d.Kb_a) * kFragFloats + 16 * a->S) * sizeof(float);
+    const size_t lds = ((size_t)(6 * d.Kb_h + 3 * d.Kb_hd + 2 * d.Kb_s + 2 * d.Kb_a) * kFragFloats + 16 * a->S +
+                        kSplitScratchFloats) * sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_imagine_backward: needs %zu B of LDS", lds);
     if (lds > 64 * 1024 && allow_big_lds(imagine_bwd_kernel)) return -1;
     hipLaunchKernelGGL(imagine_bwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);

@@ -8,12 +8,13 @@ namespace bd {
 
 // ---- forward --------------------------------------------------------------------------------------
 template <int RT, int NI>
-__global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, int KbA) {
+__global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, int KbA, int KbB) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int row0 = blockIdx.x * 16 * RT;
     float* cur = smem;                                   // inputs of even layers
     float* nxt = smem + (size_t)RT * KbA * kFragFloats;  // inputs of odd layers
+    float* scratch = nxt + (size_t)RT * KbB * kFragFloats;   // split-K partials for narrow layers
     load_tile_concat<RT>(cur, cdiv(a.w0 + a.w1, 16), row0, a.M, a.in0, a.ld0, a.w0, a.in1, a.ld1, a.w1);
     lds_barrier();
     for (int l = 0; l < a.n_layers; ++l) {
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, in
                     if (last) a.out[(size_t)grow * a.ldo + col] = v;
                 }
             }
-        });
+        }, scratch);
         lds_barrier();
         float* t = cur; cur = nxt; nxt = t;
     }
@@ -41,12 +42,13 @@ __global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, in
 
 // ---- backward (dgrad chain) -------------------------------------------------------------------------
 template <int RT, int NI>
-__global__ __launch_bounds__(kThreads) void mlp_bwd_kernel(bd_mlp_bwd_args a, int KbA) {
+__global__ __launch_bounds__(kThreads) void mlp_bwd_kernel(bd_mlp_bwd_args a, int KbA, int KbB) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int row0 = blockIdx.x * 16 * RT;
     float* cur = smem;
     float* nxt = smem + (size_t)RT * KbA * kFragFloats;
+    float* scratch = nxt + (size_t)RT * KbB * kFragFloats;   // split-K partials for narrow layers
     // d(pre-activation) of the last layer
     {
         const bd_layer_bwd L = a.layer[a.n_layers - 1];
@@ -99,16 +101,16 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_kernel(bd_mlp_bwd_args a, in
                 else if (col < a.w0 + a.w1) { if (a.din1) p = a.din1 + (size_t)grow * a.ld1 + (col - a.w0); }
                 if (p) *p = a.accumulate ? *p + acc[r] : acc[r];
             }
-        });
+        }, scratch);
     }
 }
 
 template <class K, class Args>
 static int launch_chain(K kernel, const char* name, int M, int RT, int KbA, int KbB, hipStream_t s, const Args& args) {
-    const size_t lds = (size_t)RT * (KbA + KbB) * kFragFloats * sizeof(float);
+    const size_t lds = ((size_t)RT * (KbA + KbB) * kFragFloats + kSplitScratchFloats) * sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "%s: chain needs %zu B of LDS (> %d)", name, lds, kMaxLds);
     if (lds > 64 * 1024 && allow_big_lds(kernel)) return -1;
-    hipLaunchKernelGGL(kernel, dim3(cdiv(M, 16 * RT)), dim3(kThreads), lds, s, args, KbA);
+    hipLaunchKernelGGL(kernel, dim3(cdiv(M, 16 * RT)), dim3(kThreads), lds, s, args, KbA, KbB);
     BD_CHECK_LAUNCH(name);
     return 0;
 }
@@ -116,7 +118,7 @@ static int launch_chain(K kernel, const char* name, int M, int RT, int KbA, int 
 static int pick_rt(int M, int KbA, int KbB) {
     const int tiles = cdiv(M, 16);
     int rt = tiles >= 1024 ? 2 : 1;
-    while (rt > 1 && (size_t)rt * (KbA + KbB) * kFragFloats * sizeof(float) > 64 * 1024) rt >>= 1;
+    while (rt > 1 && ((size_t)rt * (KbA + KbB) * kFragFloats + kSplitScratchFloats) * sizeof(float) > 64 * 1024) rt >>= 1;
     return rt;
 }
 

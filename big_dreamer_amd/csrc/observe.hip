@@ -34,6 +34,7 @@ __global__ __launch_bounds__(kThreads) void observe_fwd_kernel(bd_observe_fwd_ar
     float* sf = qf + d.Kb_hd * kFragFloats;
     float* af = sf + d.Kb_s * kFragFloats;
     float* s_plain = af + d.Kb_a * kFragFloats;   // [16][S] unmasked posterior state of the previous step
+    float* scratch = s_plain + 16 * a.S;          // split-K partials (kSplitScratchFloats)
 
     load_tile_concat<1>(h_cur, d.Kb_h, row0, a.B, a.init_belief, a.Be, a.Be, nullptr, 0, 0);
     for (int i = threadIdx.x; i < 16 * a.S; i += blockDim.x) {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kThreads) void observe_fwd_kernel(bd_observe_fwd_ar
                     }
                     s_plain[row * a.S + col] = st;
                 }
-            });
+            }, scratch);
         }
         lds_barrier();
         float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(kThreads) void observe_bwd_kernel(bd_observe_bwd_ar
     float* dM = dQ + d.Kb_hd * kFragFloats;            // Kb_s
     float* dRaw = dM + ns;
     float* ds_plain = dRaw + ns;                       // [16][S] carry: d loss / d posterior_state_t
+    float* scratch = ds_plain + 16 * a.S;              // split-K partials (kSplitScratchFloats)
 
     for (int i = threadIdx.x; i < nh; i += blockDim.x) dhc[i] = 0.f;
     for (int i = threadIdx.x; i < 16 * a.S; i += blockDim.x) ds_plain[i] = 0.f;
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(kThreads) void observe_bwd_kernel(bd_observe_bwd_ar
                     ds_plain[row * a.S + col] = v;
                 }
             }
-        });
+        }, scratch);
         lds_barrier();
     }
 }
@@ -284,7 +286,8 @@ int bd_observe_forward(const bd_observe_fwd_args* a, void* stream) {
                "bd_observe_forward: missing inputs");
     BD_REQUIRE(a->feat && a->post_mean && a->post_std, "bd_observe_forward: missing outputs");
     const ObsDims d(a->Be, a->S, a->A, a->Hd);
-    const size_t lds = ((size_t)(3 * d.Kb_h + d.Kb_hd + d.Kb_s + d.Kb_a) * kFragFloats + 16 * a->S) * sizeof(float);
+    const size_t lds = ((size_t)(3 * d.Kb_h + d.Kb_hd + d.Kb_s + d.Kb_a) * kFragFloats + 16 * a->S + kSplitScratchFloats) *
+                       sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_observe_forward: needs %zu B of LDS", lds);
     if (lds > 64 * 1024 && allow_big_lds(observe_fwd_kernel)) return -1;
     hipLaunchKernelGGL(observe_fwd_kernel, dim3(cdiv(a->B, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);
@@ -300,7 +303,8 @@ int bd_observe_backward(const bd_observe_bwd_args* a, void* stream) {
                "bd_observe_backward: missing forward tensors");
     BD_REQUIRE(a->d_embed_pre && a->d_gi && a->d_gh && a->d_q1_pre && a->d_q2_out, "bd_observe_backward: missing outputs");
     const ObsDims d(a->Be, a->S, a->A, a->Hd);
-    const size_t lds = ((size_t)(6 * d.Kb_h + d.Kb_hd + 2 * d.Kb_s) * kFragFloats + 16 * a->S) * sizeof(float);
+    const size_t lds = ((size_t)(6 * d.Kb_h + d.Kb_hd + 2 * d.Kb_s) * kFragFloats + 16 * a->S + kSplitScratchFloats) *
+                       sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_observe_backward: needs %zu B of LDS", lds);
     if (lds > 64 * 1024 && allow_big_lds(observe_bwd_kernel)) return -1;
     hipLaunchKernelGGL(observe_bwd_kernel, dim3(cdiv(a->B, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);
