@@ -102,6 +102,11 @@ _SIGS = {
     "bd_wgrad": (I32, [P, I32, P, I32, I32, I32, I32, P, I32, P, I32, P, C.c_size_t, P]),
     "bd_observe_forward": (I32, [C.POINTER(ObserveFwdArgs), P]),
     "bd_observe_backward": (I32, [C.POINTER(ObserveBwdArgs), P]),
+    "bd_observe_cluster_size": (I32, [I32]),
+    "bd_observe_cluster_ws_floats": (C.c_size_t, [I32, I32]),
+    "bd_observe_forward_cluster": (I32, [C.POINTER(ObserveFwdArgs), P, C.c_size_t, P]),
+    "bd_observe_backward_cluster": (I32, [C.POINTER(ObserveBwdArgs), P, C.c_size_t, P]),
+    "bd_observe_cluster_status": (I32, [P, I32, P]),
     "bd_gauss_head_forward": (I32, [P, P, I32, I32, F32, P, P, P, P]),
     "bd_gauss_head_backward": (I32, [P, P, P, P, P, I32, I32, P, P]),
     "bd_imagine_forward": (I32, [C.POINTER(ImagineFwdArgs), P]),

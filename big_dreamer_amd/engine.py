@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -94,6 +95,9 @@ class DreamerEngine:
         self.red_ws = torch.zeros(int(lib.bd_reduce_ws_floats()), dtype=torch.float32, device=self.dev)
         self._wgrad_ws = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self._buf: Dict[str, torch.Tensor] = {}
+        # cluster variant of the observe scan (several CUs per 16-row tile): on unless BD_OBS_CLUSTER=0
+        self.use_obs_cluster = os.environ.get("BD_OBS_CLUSTER", "1") != "0" and int(lib.bd_observe_cluster_size(d.Be)) > 0
+        self._obs_ws: Optional[torch.Tensor] = None
         self._timers_on = False
         self._timer_events: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
         self._build_pack_tables()
@@ -320,8 +324,26 @@ class DreamerEngine:
             a.sv_s, a.sv_x = ptr(self.buf("sv_s", M, d.S)), ptr(self.buf("sv_x", M, d.Be))
             a.sv_gates, a.sv_q = ptr(self.buf("sv_gates", M, 4 * d.Be)), ptr(self.buf("sv_q", M, d.Hd))
         with self.span("observe_fwd"):
-            cabi.check(lib.bd_observe_forward(C.byref(a), cabi.stream()))
+            if self._cluster_ok(B):
+                ws = self._cluster_ws(B)
+                cabi.check(lib.bd_observe_forward_cluster(C.byref(a), ptr(ws), ws.numel(), cabi.stream()))
+            else:
+                cabi.check(lib.bd_observe_forward(C.byref(a), cabi.stream()))
         return feat, qm, qs
+
+    def _cluster_ok(self, B: int) -> bool:
+        return self.use_obs_cluster and ((B + 15) // 16) * int(lib.bd_observe_cluster_size(self.d.Be)) <= 256
+
+    def _cluster_ws(self, B: int) -> torch.Tensor:
+        need = int(lib.bd_observe_cluster_ws_floats(B, self.d.Be))
+        if self._obs_ws is None or self._obs_ws.numel() < need:
+            self._obs_ws = torch.zeros(need, dtype=torch.float32, device=self.dev)
+        return self._obs_ws
+
+    def cluster_status(self, B: int) -> None:
+        """Raise if a member of the last cluster launch timed out waiting for its peers (synchronises)."""
+        if self._obs_ws is not None:
+            cabi.check(lib.bd_observe_cluster_status(ptr(self._obs_ws), B, cabi.stream()))
 
     def prior_head(self, feat, M: int, eps, tag: str = ""):
         """belief_prior on all beliefs at once (src/models.py:256): returns state, mean, std [M x S]."""
@@ -471,7 +493,11 @@ class DreamerEngine:
         d_q1, d_q2 = self.buf("d_q1_pre", N, d.Hd), self.buf("d_q2_out", N, 2 * d.S)
         b.d_embed_pre, b.d_gi, b.d_gh, b.d_q1_pre, b.d_q2_out = ptr(d_e), ptr(d_gi), ptr(d_gh), ptr(d_q1), ptr(d_q2)
         with self.span("observe_bwd"):
-            cabi.check(lib.bd_observe_backward(C.byref(b), st))
+            if self._cluster_ok(B):
+                ws_c = self._cluster_ws(B)
+                cabi.check(lib.bd_observe_backward_cluster(C.byref(b), ptr(ws_c), ws_c.numel(), st))
+            else:
+                cabi.check(lib.bd_observe_backward(C.byref(b), st))
         # encoder (+ hoisted projection as its last layer)
         enc_layers = self._dense_spec("encoder", "enc", d.O, d.E) + [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)]
         enc_acts = [self._buf[f"enc_act{l}"] for l in range(DENSE_LAYERS)]
