@@ -172,11 +172,31 @@ struct LinFrag {
     floatx4 b[NI];
 };
 
+// Epilogue operands (saved activations, noise, hoisted projections: cold, streamed-once HBM data) must be in
+// flight BEFORE the contraction, or every phase pays an extra serial HBM round trip (~5k cycles, measured with
+// s_memtime stamps).  `pre(rt, nb)` is called per accumulator before the K loop and its result is handed to
+// `epi(rt, nb, acc, pre_result)`.  NoPre is the default for epilogues without such operands.
+struct NoPreVal {};
+struct Pre4 {            // four scalars, one per accumulator row r = 0..3
+    float v[4];
+};
+struct PreGate {         // GRU backward operands per accumulator row: r, z, n, (W_hn h + b_hn), h_prev, d feat
+    float r[4], z[4], n[4], hn[4], hprev[4], dfeat[4];
+};
+struct NoPre {
+    __device__ __forceinline__ NoPreVal operator()(int, int) const { return NoPreVal{}; }
+};
+
 // NI column blocks nb0, nb0+kWaves, ... of this wave (all valid), RT row tiles, all segments.
-template <int NSEG, int RT, int NI, int D, class Epi>
+template <int NSEG, int RT, int NI, int D, class Pre, class Epi>
 __device__ __forceinline__ void linear_blocks(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, int nb0,
-                                              Epi&& epi) {
+                                              Pre&& pre, Epi&& epi) {
     const int lane = threadIdx.x & 63;
+    decltype(pre(0, 0)) pf[NI][RT];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) pf[i][rt] = pre(rt, nb0 + i * kWaves);
     constexpr bool kSplit = (NI * RT == 1);   // a lone chain would pay the 40-cycle dependent-MFMA latency
     floatx4 acc[NI][RT];
     floatx4 acc2 = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -223,7 +243,7 @@ __device__ __forceinline__ void linear_blocks(const Seg (&seg)[NSEG], const floa
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) epi(rt, nb0 + i * kWaves, acc[i][rt]);
+        for (int rt = 0; rt < RT; ++rt) epi(rt, nb0 + i * kWaves, acc[i][rt], pf[i][rt]);
 }
 
 // ---- split-K over waves for narrow outputs ----------------------------------------------------------------
@@ -236,12 +256,21 @@ __device__ __forceinline__ void linear_blocks(const Seg (&seg)[NSEG], const floa
 constexpr int kSplitPairs = 2;
 constexpr int kSplitScratchFloats = kWaves * kSplitPairs * 2 * kFragFloats;   // dual form needs 2 outputs per pair
 
-template <int RT, int NSEG, class Epi>
+template <int RT, int NSEG, class Pre, class Epi>
 __device__ __forceinline__ void tile_linear_splitk(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
-                                                   float* __restrict__ scratch, Epi&& epi) {
+                                                   float* __restrict__ scratch, Pre&& pre, Epi&& epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Nb = (N + 15) >> 4;
     const int P = Nb * RT;                      // <= kSplitPairs (checked by the caller)
+    // the reducing waves fetch their bias and epilogue operands up front
+    const int my_nb = wave / RT, my_rt = wave - my_nb * RT;
+    decltype(pre(0, 0)) pf{};
+    float my_bias = 0.f;
+    if (wave < P) {
+        pf = pre(my_rt, my_nb);
+        const int col = my_nb * 16 + (lane & 15);
+        my_bias = (bias != nullptr && col < N) ? bias[col] : 0.f;
+    }
     floatx4 acc[kSplitPairs];
 #pragma unroll
     for (int p = 0; p < kSplitPairs; ++p) acc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -269,32 +298,36 @@ __device__ __forceinline__ void tile_linear_splitk(const Seg (&seg)[NSEG], const
         if (p < P) S4[(wave * kSplitPairs + p) * 64 + lane] = acc[p];
     lds_barrier();
     if (wave < P) {
-        const int nb = wave / RT, rt = wave - nb * RT;
-        const int col = nb * 16 + (lane & 15);
-        const float b = (bias != nullptr && col < N) ? bias[col] : 0.f;
-        floatx4 r = floatx4{b, b, b, b};
+        floatx4 r = floatx4{my_bias, my_bias, my_bias, my_bias};
         for (int w = 0; w < kWaves; ++w) r += S4[(w * kSplitPairs + wave) * 64 + lane];
-        epi(rt, nb, r);
+        epi(my_rt, my_nb, r, pf);
     }
 }
 
 // Each wave owns column blocks nb = wave, wave+kWaves, ...; two are kept in flight where two exist (independent
 // MFMA chains: 16x16x4 f32 issues every 32 cycles but a dependent one needs 40), the odd last one runs alone.
 // epi(rt, nb, acc): lane holds out[row = 16*rt + 4*(lane>>4) + r][col = nb*16 + (lane&15)], r = 0..3.
-template <int RT, int NSEG, class Epi>
-__device__ __forceinline__ void tile_linear_g(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Epi&& epi,
-                                              float* __restrict__ scratch = nullptr) {
+template <int RT, int NSEG, class Pre, class Epi>
+__device__ __forceinline__ void tile_linear_pre(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Pre&& pre,
+                                                Epi&& epi, float* __restrict__ scratch = nullptr) {
     const int wave = threadIdx.x >> 6;
     const int Nb = (N + 15) >> 4;
     if (scratch != nullptr && Nb * RT <= kSplitPairs) {   // workgroup-uniform
-        tile_linear_splitk<RT, NSEG>(seg, bias, N, scratch, epi);
+        tile_linear_splitk<RT, NSEG>(seg, bias, N, scratch, pre, epi);
         return;
     }
     constexpr int D = 2;
     for (int nb0 = wave; nb0 < Nb; nb0 += 2 * kWaves) {
-        if (nb0 + kWaves < Nb) linear_blocks<NSEG, RT, 2, D>(seg, bias, N, nb0, epi);
-        else linear_blocks<NSEG, RT, 1, D>(seg, bias, N, nb0, epi);
+        if (nb0 + kWaves < Nb) linear_blocks<NSEG, RT, 2, D>(seg, bias, N, nb0, pre, epi);
+        else linear_blocks<NSEG, RT, 1, D>(seg, bias, N, nb0, pre, epi);
     }
+}
+
+template <int RT, int NSEG, class Epi>
+__device__ __forceinline__ void tile_linear_g(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Epi&& epi,
+                                              float* __restrict__ scratch = nullptr) {
+    tile_linear_pre<RT, NSEG>(seg, bias, N, NoPre{}, [&](int rt, int nb, floatx4 acc, NoPreVal) { epi(rt, nb, acc); },
+                              scratch);
 }
 
 // single-segment convenience forms
@@ -326,13 +359,21 @@ struct DualFrag {
     floatx4 a, p, q;
 };
 
-template <int NSEG, class Epi>
-__device__ __forceinline__ void tile_linear_dual(const Seg2 (&seg)[NSEG], const float* __restrict__ bias0,
-                                                 const float* __restrict__ bias1, int N, Epi&& epi,
-                                                 float* __restrict__ scratch = nullptr) {
+template <int NSEG, class Pre, class Epi>
+__device__ __forceinline__ void tile_linear_dual_pre(const Seg2 (&seg)[NSEG], const float* __restrict__ bias0,
+                                                     const float* __restrict__ bias1, int N, Pre&& pre, Epi&& epi,
+                                                     float* __restrict__ scratch = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Nb = (N + 15) >> 4;
     if (scratch != nullptr && Nb <= kSplitPairs) {   // split-K over waves (see tile_linear_splitk); both W0, W1 given
+        decltype(pre(0)) pf{};
+        float mb0 = 0.f, mb1 = 0.f;
+        if (wave < Nb) {                              // reducing waves: bias + epilogue operands up front
+            pf = pre(wave);
+            const int col = wave * 16 + (lane & 15);
+            mb0 = (bias0 != nullptr && col < N) ? bias0[col] : 0.f;
+            mb1 = (bias1 != nullptr && col < N) ? bias1[col] : 0.f;
+        }
         floatx4 a0[kSplitPairs], a1[kSplitPairs];
 #pragma unroll
         for (int p = 0; p < kSplitPairs; ++p) a0[p] = a1[p] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -366,19 +407,17 @@ __device__ __forceinline__ void tile_linear_dual(const Seg2 (&seg)[NSEG], const 
             }
         lds_barrier();
         if (wave < Nb) {
-            const int col = wave * 16 + (lane & 15);
-            const float b0 = (bias0 != nullptr && col < N) ? bias0[col] : 0.f;
-            const float b1 = (bias1 != nullptr && col < N) ? bias1[col] : 0.f;
-            floatx4 r0 = floatx4{b0, b0, b0, b0}, r1 = floatx4{b1, b1, b1, b1};
+            floatx4 r0 = floatx4{mb0, mb0, mb0, mb0}, r1 = floatx4{mb1, mb1, mb1, mb1};
             for (int w = 0; w < kWaves; ++w) {
                 r0 += S4[((w * kSplitPairs + wave) * 2 + 0) * 64 + lane];
                 r1 += S4[((w * kSplitPairs + wave) * 2 + 1) * 64 + lane];
             }
-            epi(wave, r0, r1);
+            epi(wave, r0, r1, pf);
         }
         return;
     }
     for (int nb = wave; nb < Nb; nb += kWaves) {
+        const auto pf = pre(nb);
         const int col = nb * 16 + (lane & 15);
         const float b0 = (bias0 != nullptr && col < N) ? bias0[col] : 0.f;
         const float b1 = (bias1 != nullptr && col < N) ? bias1[col] : 0.f;
@@ -414,8 +453,19 @@ __device__ __forceinline__ void tile_linear_dual(const Seg2 (&seg)[NSEG], const 
                 }
             }
         }
-        epi(nb, acc0, acc1);
+        epi(nb, acc0, acc1, pf);
     }
+}
+
+struct NoPre1 {
+    __device__ __forceinline__ NoPreVal operator()(int) const { return NoPreVal{}; }
+};
+template <int NSEG, class Epi>
+__device__ __forceinline__ void tile_linear_dual(const Seg2 (&seg)[NSEG], const float* __restrict__ bias0,
+                                                 const float* __restrict__ bias1, int N, Epi&& epi,
+                                                 float* __restrict__ scratch = nullptr) {
+    tile_linear_dual_pre<NSEG>(seg, bias0, bias1, N, NoPre1{},
+                               [&](int nb, floatx4 a0, floatx4 a1, NoPreVal) { epi(nb, a0, a1); }, scratch);
 }
 
 // ---- GRU cell (nn.GRUCell, src/models.py:149,252): four accumulators per output column block ----------
@@ -484,10 +534,10 @@ struct GruBwdFrag {
     floatx4 ar, az, ai, ah, bir, biz, bin, bhr, bhz, bhn;
 };
 
-template <class Epi>
+template <class Pre, class Epi>
 __device__ __forceinline__ void gru_tile_bwd(const float* __restrict__ dR, const float* __restrict__ dZ,
                                              const float* __restrict__ dNI, const float* __restrict__ dNH, int Kb,
-                                             int Be, const GruWT& w, Epi&& epi) {
+                                             int Be, const GruWT& w, Pre&& pre, Epi&& epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Nb = (Be + 15) >> 4;
     const floatx4* __restrict__ R4 = reinterpret_cast<const floatx4*>(dR) + lane;
@@ -495,6 +545,7 @@ __device__ __forceinline__ void gru_tile_bwd(const float* __restrict__ dR, const
     const floatx4* __restrict__ I4 = reinterpret_cast<const floatx4*>(dNI) + lane;
     const floatx4* __restrict__ H4 = reinterpret_cast<const floatx4*>(dNH) + lane;
     for (int nb = wave; nb < Nb; nb += kWaves) {
+        const auto pf = pre(nb);      // epilogue operands in flight before the contraction
         floatx4 DX = floatx4{0.f, 0.f, 0.f, 0.f}, DH = floatx4{0.f, 0.f, 0.f, 0.f};
         floatx4 DX2 = DX, DH2 = DH;   // second chain per output: consecutive MFMAs stay independent
         const size_t off = (size_t)nb * Kb * 64 + lane;
@@ -521,7 +572,7 @@ __device__ __forceinline__ void gru_tile_bwd(const float* __restrict__ dR, const
                     DH = mfma16(f.ah[j], f.bhn[j], DH);
                 }
             });
-        epi(nb, DX + DX2, DH + DH2);
+        epi(nb, DX + DX2, DH + DH2, pf);
     }
 }
 

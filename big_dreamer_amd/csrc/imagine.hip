@@ -85,23 +85,42 @@ struct HiddenEpi {
 // next contraction (dst may be null) and store for bd_wgrad (out may be null).
 struct DpreEpi {
     float* dst;
-    const float* saved;
     float* out;
     size_t tn;
     int width, rows, row0, lane;
-    __device__ __forceinline__ void operator()(int nb, floatx4 acc) const {
+    __device__ __forceinline__ void operator()(int, int nb, floatx4 acc, const Pre4& p) const {
         const int col = nb * 16 + (lane & 15);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int grow = row0 + 4 * (lane >> 4) + r;
             float v = 0.f;
             if (grow < rows && col < width) {
-                v = acc[r] * elu_grad_from_out(saved[(tn + grow) * width + col]);
+                v = acc[r] * elu_grad_from_out(p.v[r]);
                 if (out) out[(tn + grow) * width + col] = v;
             }
             if (dst) dst[acc_frag_off(nb, lane, r)] = v;
         }
     }
+};
+// the saved ELU outputs that DpreEpi needs, fetched before the contraction
+struct DprePre {
+    const float* saved;
+    size_t tn;
+    int width, rows, row0, lane;
+    __device__ __forceinline__ Pre4 operator()(int, int nb) const {
+        Pre4 p;
+        const int col = nb * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int grow = row0 + 4 * (lane >> 4) + r;
+            p.v[r] = (grow < rows && col < width) ? saved[(tn + grow) * width + col] : 1.f;
+        }
+        return p;
+    }
+};
+
+struct PreAct {          // operands of the action-sample backward per accumulator row
+    float act[4], th[4], sg[4], dm[4], ds[4], eps[4];
 };
 
 __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_args a) {
@@ -164,30 +183,43 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         // ---- actor output, action sample ----
         {
             const Seg2 segs[1] = {{bufB, a.w_a4m, a.w_a4s, d.Kb_hd}};
-            tile_linear_dual<1>(segs, a.b_a4, a.b_a4 + A, A, [&](int nb, floatx4 Mn, floatx4 Rw) {
-                const int col = nb * 16 + (lane & 15);
+            tile_linear_dual_pre<1>(
+                segs, a.b_a4, a.b_a4 + A, A,
+                [&](int nb) {
+                    Pre4 p;
+                    const int col = nb * 16 + (lane & 15);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * (lane >> 4) + r, grow = row0 + row;
-                    float act = 0.f;
-                    if (grow < a.N && col < A) {
-                        const float th = tanhf(Mn[r] / a.act_mean_scale);
-                        const float mean = a.act_mean_scale * th;
-                        const float pre = Rw[r] + a.act_raw_init_std;
-                        const float sd = softplusf(pre) + a.act_min_std;
-                        act = tanhf(mean + sd * a.eps_action[(tn + grow) * A + col]);
-                        a.action[(tn + grow) * A + col] = act;
-                        mean_s[row * A + col] = mean;
-                        std_s[row * A + col] = sd;
-                        if (a.sv_act_stats) {
-                            float* st = a.sv_act_stats + (tn + grow) * 4 * A + col;
-                            st[0] = th;
-                            st[A] = sigmoidf(pre);
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = row0 + 4 * (lane >> 4) + r;
+                        p.v[r] = (grow < a.N && col < A) ? a.eps_action[(tn + grow) * A + col] : 0.f;
                     }
-                    af[acc_frag_off(nb, lane, r)] = act;
-                }
-            }, scratch);
+                    return p;
+                },
+                [&](int nb, floatx4 Mn, floatx4 Rw, const Pre4& p) {
+                    const int col = nb * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 4 * (lane >> 4) + r, grow = row0 + row;
+                        float act = 0.f;
+                        if (grow < a.N && col < A) {
+                            const float th = tanhf(Mn[r] / a.act_mean_scale);
+                            const float mean = a.act_mean_scale * th;
+                            const float pre = Rw[r] + a.act_raw_init_std;
+                            const float sd = softplusf(pre) + a.act_min_std;
+                            act = tanhf(mean + sd * p.v[r]);
+                            a.action[(tn + grow) * A + col] = act;
+                            mean_s[row * A + col] = mean;
+                            std_s[row * A + col] = sd;
+                            if (a.sv_act_stats) {
+                                float* st = a.sv_act_stats + (tn + grow) * 4 * A + col;
+                                st[0] = th;
+                                st[A] = sigmoidf(pre);
+                            }
+                        }
+                        af[acc_frag_off(nb, lane, r)] = act;
+                    }
+                },
+                scratch);
         }
         BD_STAMP(4);
         lds_barrier();
@@ -281,23 +313,36 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         BD_STAMP(12);
         {
             const Seg2 segs[1] = {{bufA, a.w_p2m, a.w_p2s, d.Kb_hd}};
-            tile_linear_dual<1>(segs, a.b_p2, a.b_p2 + a.S, a.S, [&](int nb, floatx4 Mn, floatx4 Rw) {
-                const int col = nb * 16 + (lane & 15);
+            tile_linear_dual_pre<1>(
+                segs, a.b_p2, a.b_p2 + a.S, a.S,
+                [&](int nb) {
+                    Pre4 p;
+                    const int col = nb * 16 + (lane & 15);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int grow = row0 + 4 * (lane >> 4) + r;
-                    float st = 0.f;
-                    if (grow < a.N && col < a.S) {
-                        const size_t i = (tn + grow) * a.S + col;
-                        const float sd = softplusf(Rw[r]) + a.min_std;
-                        st = Mn[r] + sd * a.eps_prior[i];
-                        if (a.prior_mean) a.prior_mean[i] = Mn[r];
-                        a.prior_std[i] = sd;
-                        a.feat[(tn + grow) * F + a.Be + col] = st;
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = row0 + 4 * (lane >> 4) + r;
+                        p.v[r] = (grow < a.N && col < a.S) ? a.eps_prior[(tn + grow) * a.S + col] : 0.f;
                     }
-                    sf[acc_frag_off(nb, lane, r)] = st;
-                }
-            }, scratch);
+                    return p;
+                },
+                [&](int nb, floatx4 Mn, floatx4 Rw, const Pre4& p) {
+                    const int col = nb * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = row0 + 4 * (lane >> 4) + r;
+                        float st = 0.f;
+                        if (grow < a.N && col < a.S) {
+                            const size_t i = (tn + grow) * a.S + col;
+                            const float sd = softplusf(Rw[r]) + a.min_std;
+                            st = Mn[r] + sd * p.v[r];
+                            if (a.prior_mean) a.prior_mean[i] = Mn[r];
+                            a.prior_std[i] = sd;
+                            a.feat[(tn + grow) * F + a.Be + col] = st;
+                        }
+                        sf[acc_frag_off(nb, lane, r)] = st;
+                    }
+                },
+                scratch);
         }
         BD_STAMP(13);
         lds_barrier();
@@ -338,9 +383,10 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
     const GruWT gw{a.wt_ir, a.wt_iz, a.wt_in, a.wt_hr, a.wt_hz, a.wt_hn};
     const size_t act_stride = (size_t)a.Hm * a.N * a.Hd;
 
-    auto dpre_epi = [&](float* dst, const float* saved, float* out, size_t tn, int width) {
-        return DpreEpi{dst, saved, out, tn, width, a.N, row0, lane};
+    auto dpre_epi = [&](float* dst, float* out, size_t tn, int width) {
+        return DpreEpi{dst, out, tn, width, a.N, row0, lane};
     };
+    auto dpre_pre = [&](const float* saved, size_t tn, int width) { return DprePre{saved, tn, width, a.N, row0, lane}; };
 
     for (int t = a.Hm - 1; t >= 0; --t) {
         const size_t tn = (size_t)t * a.N;
@@ -361,50 +407,83 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
         // ---- 2: prior hidden ----
         {
             const Seg segs[2] = {{dM, a.wt_p2m, d.Kb_s}, {dRaw, a.wt_p2s, d.Kb_s}};
-            tile_linear_seg<kNI, 2>(segs, nullptr, a.Hd, dpre_epi(dP, a.sv_p, nullptr, tn, a.Hd));
+            tile_linear_pre<1, 2>(segs, nullptr, a.Hd, dpre_pre(a.sv_p, tn, a.Hd), dpre_epi(dP, nullptr, tn, a.Hd));
         }
         lds_barrier();
         // ---- 3: total d belief_{t+1}; GRU gates ----
-        tile_linear<1, kNI>(dP, d.Kb_hd, a.wt_p1, nullptr, a.Be, [&](int, int nb, floatx4 acc) {
-            const int col = nb * 16 + (lane & 15);
+        {
+            const Seg segs3[1] = {{dP, a.wt_p1, d.Kb_hd}};
+            tile_linear_pre<1, 1>(
+                segs3, nullptr, a.Be,
+                [&](int, int nb) {
+                    PreGate p;
+                    const int col = nb * 16 + (lane & 15);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int grow = row0 + 4 * (lane >> 4) + r;
-                const int off = acc_frag_off(nb, lane, r);
-                float vr = 0.f, vz = 0.f, vni = 0.f, vnh = 0.f, carry = 0.f;
-                if (grow < a.N && col < a.Be) {
-                    const float dh = acc[r] + dhc[off] + a.dfeat[(tn + grow) * F + col];
-                    const float* g = a.sv_gates + (tn + grow) * 4 * a.Be + col;
-                    const float rr = g[0], zz = g[a.Be], nn = g[2 * a.Be], hn = g[3 * a.Be];
-                    const float hprev = t > 0 ? a.feat[(tn - a.N + grow) * F + col] : a.start_feat[(size_t)grow * F + col];
-                    const float dn = dh * (1.f - zz);
-                    const float dz = dh * (hprev - nn);
-                    vni = dn * (1.f - nn * nn);
-                    vnh = vni * rr;
-                    vr = vni * hn * rr * (1.f - rr);
-                    vz = dz * zz * (1.f - zz);
-                    carry = dh * zz;
-                }
-                dR[off] = vr; dZ[off] = vz; dNI[off] = vni; dNH[off] = vnh;
-                dhc[off] = carry;
-            }
-        });
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = row0 + 4 * (lane >> 4) + r;
+                        const bool ok = grow < a.N && col < a.Be;
+                        const float* g = a.sv_gates + (tn + grow) * 4 * a.Be + col;
+                        p.r[r] = ok ? g[0] : 0.f;
+                        p.z[r] = ok ? g[a.Be] : 0.f;
+                        p.n[r] = ok ? g[2 * a.Be] : 0.f;
+                        p.hn[r] = ok ? g[3 * a.Be] : 0.f;
+                        p.hprev[r] = !ok ? 0.f : (t > 0 ? a.feat[(tn - a.N + grow) * F + col]
+                                                        : a.start_feat[(size_t)grow * F + col]);
+                        p.dfeat[r] = ok ? a.dfeat[(tn + grow) * F + col] : 0.f;
+                    }
+                    return p;
+                },
+                [&](int, int nb, floatx4 acc, const PreGate& p) {
+                    const int col = nb * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = row0 + 4 * (lane >> 4) + r;
+                        const int off = acc_frag_off(nb, lane, r);
+                        float vr = 0.f, vz = 0.f, vni = 0.f, vnh = 0.f, carry = 0.f;
+                        if (grow < a.N && col < a.Be) {
+                            const float dh = acc[r] + dhc[off] + p.dfeat[r];
+                            const float rr = p.r[r], zz = p.z[r], nn = p.n[r], hn = p.hn[r];
+                            const float dn = dh * (1.f - zz);
+                            const float dz = dh * (p.hprev[r] - nn);
+                            vni = dn * (1.f - nn * nn);
+                            vnh = vni * rr;
+                            vr = vni * hn * rr * (1.f - rr);
+                            vz = dz * zz * (1.f - zz);
+                            carry = dh * zz;
+                        }
+                        dR[off] = vr; dZ[off] = vz; dNI[off] = vni; dNH[off] = vnh;
+                        dhc[off] = carry;
+                    }
+                });
+        }
         lds_barrier();
         // ---- 4: through W_ih / W_hh ----
-        gru_tile_bwd(dR, dZ, dNI, dNH, d.Kb_h, a.Be, gw, [&](int nb, floatx4 DX, floatx4 DH) {
-            const int col = nb * 16 + (lane & 15);
+        gru_tile_bwd(
+            dR, dZ, dNI, dNH, d.Kb_h, a.Be, gw,
+            [&](int nb) {
+                Pre4 p;
+                const int col = nb * 16 + (lane & 15);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int grow = row0 + 4 * (lane >> 4) + r;
-                const int off = acc_frag_off(nb, lane, r);
-                float de = 0.f;
-                if (grow < a.N && col < a.Be) {
-                    de = DX[r] * elu_grad_from_out(a.sv_x[(tn + grow) * a.Be + col]);
-                    dhc[off] += DH[r];
+                for (int r = 0; r < 4; ++r) {
+                    const int grow = row0 + 4 * (lane >> 4) + r;
+                    p.v[r] = (grow < a.N && col < a.Be) ? a.sv_x[(tn + grow) * a.Be + col] : 1.f;
                 }
-                dE[off] = de;
-            }
-        });
+                return p;
+            },
+            [&](int nb, floatx4 DX, floatx4 DH, const Pre4& p) {
+                const int col = nb * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int grow = row0 + 4 * (lane >> 4) + r;
+                    const int off = acc_frag_off(nb, lane, r);
+                    float de = 0.f;
+                    if (grow < a.N && col < a.Be) {
+                        de = DX[r] * elu_grad_from_out(p.v[r]);
+                        dhc[off] += DH[r];
+                    }
+                    dE[off] = de;
+                }
+            });
         lds_barrier();
         // ---- 5: embed layer -> d state_t (carry) and d action_t -> actor output gradients ----
         tile_linear<1, kNI>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
@@ -416,35 +495,55 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
             }
         }, scratch);
         lds_barrier();   // the split-K scratch is reused by the next contraction
-        tile_linear<1, kNI>(dE, d.Kb_h, a.wt_embed_a, nullptr, A, [&](int, int nb, floatx4 acc) {
-            const int col = nb * 16 + (lane & 15);
+        {
+            const Seg segs5[1] = {{dE, a.wt_embed_a, d.Kb_h}};
+            tile_linear_pre<1, 1>(
+                segs5, nullptr, A,
+                [&](int, int nb) {
+                    PreAct p;
+                    const int col = nb * 16 + (lane & 15);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int grow = row0 + 4 * (lane >> 4) + r;
-                float gm = 0.f, gr = 0.f;
-                if (grow < a.N && col < A) {
-                    const size_t i = (tn + grow) * A + col;
-                    const float act = a.action[i];
-                    const float* st = a.sv_act_stats + (tn + grow) * 4 * A + col;
-                    const float th = st[0], sg = st[A], dent_dmean = st[2 * A], dent_dstd = st[3 * A];
-                    const float dxa = acc[r] * (1.f - act * act);                  // through a = tanh(x)
-                    const float dmean = dxa + a.dentropy * dent_dmean;
-                    const float dstd = dxa * a.eps_action[i] + a.dentropy * dent_dstd;
-                    gm = dmean * (1.f - th * th);      // mean = scale * tanh(m / scale)
-                    gr = dstd * sg;                    // std = softplus(r + c0) + min
-                    a.d_actor_out[(tn + grow) * 2 * A + col] = gm;
-                    a.d_actor_out[(tn + grow) * 2 * A + A + col] = gr;
-                }
-                dAm[acc_frag_off(nb, lane, r)] = gm;
-                dAr[acc_frag_off(nb, lane, r)] = gr;
-            }
-        }, scratch);
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = row0 + 4 * (lane >> 4) + r;
+                        const bool ok = grow < a.N && col < A;
+                        const size_t i = (tn + grow) * A + col;
+                        const float* st = a.sv_act_stats + (tn + grow) * 4 * A + col;
+                        p.act[r] = ok ? a.action[i] : 0.f;
+                        p.eps[r] = ok ? a.eps_action[i] : 0.f;
+                        p.th[r] = ok ? st[0] : 0.f;
+                        p.sg[r] = ok ? st[A] : 0.f;
+                        p.dm[r] = ok ? st[2 * A] : 0.f;
+                        p.ds[r] = ok ? st[3 * A] : 0.f;
+                    }
+                    return p;
+                },
+                [&](int, int nb, floatx4 acc, const PreAct& p) {
+                    const int col = nb * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = row0 + 4 * (lane >> 4) + r;
+                        float gm = 0.f, gr = 0.f;
+                        if (grow < a.N && col < A) {
+                            const float dxa = acc[r] * (1.f - p.act[r] * p.act[r]);          // through a = tanh(x)
+                            const float dmean = dxa + a.dentropy * p.dm[r];
+                            const float dstd = dxa * p.eps[r] + a.dentropy * p.ds[r];
+                            gm = dmean * (1.f - p.th[r] * p.th[r]);      // mean = scale * tanh(m / scale)
+                            gr = dstd * p.sg[r];                          // std = softplus(r + c0) + min
+                            a.d_actor_out[(tn + grow) * 2 * A + col] = gm;
+                            a.d_actor_out[(tn + grow) * 2 * A + A + col] = gr;
+                        }
+                        dAm[acc_frag_off(nb, lane, r)] = gm;
+                        dAr[acc_frag_off(nb, lane, r)] = gr;
+                    }
+                },
+                scratch);
+        }
         lds_barrier();
         // ---- 6: actor MLP backward (input detached: no gradient below layer 0) ----
         {
             const Seg segs[2] = {{dAm, a.wt_a4m, d.Kb_a}, {dAr, a.wt_a4s, d.Kb_a}};
-            tile_linear_seg<kNI, 2>(segs, nullptr, a.Hd,
-                                  dpre_epi(bufA, a.sv_actor + 3 * act_stride, a.d_actor_pre + 3 * act_stride, tn, a.Hd));
+            tile_linear_pre<1, 2>(segs, nullptr, a.Hd, dpre_pre(a.sv_actor + 3 * act_stride, tn, a.Hd),
+                                  dpre_epi(bufA, a.d_actor_pre + 3 * act_stride, tn, a.Hd));
         }
         lds_barrier();
         {
@@ -452,9 +551,8 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
             float* dst = bufB;
             for (int l = 2; l >= 0; --l) {
                 const Seg segs[1] = {{src, a.wt_a[l], d.Kb_hd}};
-                tile_linear_seg<kNI, 1>(segs, nullptr, a.Hd,
-                                      dpre_epi(l > 0 ? dst : nullptr, a.sv_actor + l * act_stride,
-                                               a.d_actor_pre + l * act_stride, tn, a.Hd));
+                tile_linear_pre<1, 1>(segs, nullptr, a.Hd, dpre_pre(a.sv_actor + l * act_stride, tn, a.Hd),
+                                      dpre_epi(l > 0 ? dst : nullptr, a.d_actor_pre + l * act_stride, tn, a.Hd));
                 lds_barrier();
                 float* tmp = src; src = dst; dst = tmp;
             }

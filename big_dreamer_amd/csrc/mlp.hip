@@ -70,21 +70,35 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_kernel(bd_mlp_bwd_args a, in
         const bd_layer_bwd L = a.layer[l];       // contraction over this layer's outputs (N) -> its inputs (K)
         const bd_layer_bwd P = a.layer[l - 1];   // whose outputs those inputs are
         const int Kb = cdiv(L.N, 16), Nb = cdiv(L.K, 16);
-        tile_linear<RT, NI>(cur, Kb, L.wt, nullptr, L.K, [&](int rt, int nb, floatx4 acc) {
-            const int c = lane & 15, col = nb * 16 + c;
+        const Seg segs[1] = {{cur, L.wt, Kb}};
+        tile_linear_pre<RT, 1>(
+            segs, nullptr, L.K,
+            [&](int rt, int nb) {            // saved activations of the previous layer: in flight before the K loop
+                Pre4 p;
+                const int col = nb * 16 + (lane & 15);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * (lane >> 4) + r;
-                const int grow = row0 + rt * 16 + row;
-                float v = 0.f;
-                if (grow < a.M && col < P.N) {
-                    v = acc[r];
-                    if (P.act) v *= elu_grad_from_out(P.saved[(size_t)grow * P.N + col]);
-                    if (P.dpre) P.dpre[(size_t)grow * P.N + col] = v;
+                for (int r = 0; r < 4; ++r) {
+                    const int grow = row0 + rt * 16 + 4 * (lane >> 4) + r;
+                    p.v[r] = (P.act && grow < a.M && col < P.N) ? P.saved[(size_t)grow * P.N + col] : 1.f;
                 }
-                nxt[(rt * Nb + nb) * kFragFloats + ((c >> 2) * 16 + row) * 4 + (c & 3)] = v;
-            }
-        });
+                return p;
+            },
+            [&](int rt, int nb, floatx4 acc, const Pre4& p) {
+                const int c = lane & 15, col = nb * 16 + c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * (lane >> 4) + r;
+                    const int grow = row0 + rt * 16 + row;
+                    float v = 0.f;
+                    if (grow < a.M && col < P.N) {
+                        v = acc[r];
+                        if (P.act) v *= elu_grad_from_out(p.v[r]);
+                        if (P.dpre) P.dpre[(size_t)grow * P.N + col] = v;
+                    }
+                    nxt[(rt * Nb + nb) * kFragFloats + ((c >> 2) * 16 + row) * 4 + (c & 3)] = v;
+                }
+            },
+            scratch);
         lds_barrier();
         float* t = cur; cur = nxt; nxt = t;
     }

@@ -239,21 +239,33 @@ __global__ __launch_bounds__(kThreads) void observe_bwd_kernel(bd_observe_bwd_ar
         });
         lds_barrier();
         // ---- 4: through W_ih / W_hh ----
-        gru_tile_bwd(dR, dZ, dNI, dNH, d.Kb_h, a.Be, gw, [&](int nb, floatx4 DX, floatx4 DH) {
-            const int col = nb * 16 + (lane & 15);
+        gru_tile_bwd(
+            dR, dZ, dNI, dNH, d.Kb_h, a.Be, gw,
+            [&](int nb) {
+                Pre4 p;
+                const int col = nb * 16 + (lane & 15);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int grow = row0 + 4 * (lane >> 4) + r;
-                const int off = acc_frag_off(nb, lane, r);
-                float de = 0.f;
-                if (grow < a.B && col < a.Be) {
-                    de = DX[r] * elu_grad_from_out(a.sv_x[(tb + grow) * a.Be + col]);
-                    a.d_embed_pre[(tb + grow) * a.Be + col] = de;
-                    dhc[off] += DH[r];
+                for (int r = 0; r < 4; ++r) {
+                    const int grow = row0 + 4 * (lane >> 4) + r;
+                    p.v[r] = (grow < a.B && col < a.Be) ? a.sv_x[(tb + grow) * a.Be + col] : 1.f;
                 }
-                dE[off] = de;
-            }
-        });
+                return p;
+            },
+            [&](int nb, floatx4 DX, floatx4 DH, const Pre4& p) {
+                const int col = nb * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int grow = row0 + 4 * (lane >> 4) + r;
+                    const int off = acc_frag_off(nb, lane, r);
+                    float de = 0.f;
+                    if (grow < a.B && col < a.Be) {
+                        de = DX[r] * elu_grad_from_out(p.v[r]);
+                        a.d_embed_pre[(tb + grow) * a.Be + col] = de;
+                        dhc[off] += DH[r];
+                    }
+                    dE[off] = de;
+                }
+            });
         lds_barrier();
         // ---- 5: d posterior_state_t through the embed layer and the nonterminal mask ----
         tile_linear<1, kNI>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {

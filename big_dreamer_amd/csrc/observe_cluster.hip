@@ -25,6 +25,16 @@
 namespace bd {
 
 constexpr int kMaxCluster = 16;
+
+#ifdef BD_STAMPS
+__device__ unsigned long long g_cstamps[64];
+#define BD_CSTAMP(slot)                                                                                  \
+    do {                                                                                                 \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && t == 5) g_cstamps[slot] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define BD_CSTAMP(slot)
+#endif
 constexpr int kLocalBlocks = 2;             // column blocks a member owns at most (host picks C accordingly)
 constexpr unsigned kSpinLimit = 1u << 22;   // ~ seconds; far beyond any legitimate wait
 
@@ -116,6 +126,7 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
 
     for (int t = 0; t < a.T; ++t) {
         const size_t tb = (size_t)t * a.B;
+        BD_CSTAMP(0);
         // ---- A: masked state / action fragments (every member) ----
         for (int i = threadIdx.x; i < 16 * d.Kb_s * 16; i += blockDim.x) {
             const int r = i / (d.Kb_s * 16), k = i - r * (d.Kb_s * 16);
@@ -134,6 +145,7 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
             af[frag_idx(r, k)] = (grow < a.B && k < a.A) ? a.actions[(tb + grow) * a.A + k] : 0.f;
         }
         lds_barrier();
+        BD_CSTAMP(1);
         // ---- B: embed (every member, full width) ----
         {
             const Seg segs[2] = {{sf, a.w_embed_s, d.Kb_s}, {af, a.w_embed_a, d.Kb_a}};
@@ -149,7 +161,20 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
             });
         }
         lds_barrier();
+        BD_CSTAMP(2);
         // ---- C: GRU, this member's column blocks, K split over the waves ----
+        const int my_nb = c + wave * C;                      // wave bi reduces block bi
+        const bool reducer = wave < kLocalBlocks && my_nb < Nb;
+        float br = 0.f, bz = 0.f, bni = 0.f, bnh = 0.f;      // reducer's biases: in flight before the contraction
+        if (reducer) {
+            const int col = my_nb * 16 + (lane & 15);
+            if (col < a.Be) {
+                br = a.b_ih[col] + a.b_hh[col];
+                bz = a.b_ih[a.Be + col] + a.b_hh[a.Be + col];
+                bni = a.b_ih[2 * a.Be + col];
+                bnh = a.b_hh[2 * a.Be + col];
+            }
+        }
         {
             const floatx4* __restrict__ H4 = reinterpret_cast<const floatx4*>(h_cur) + lane;
 #pragma unroll
@@ -184,16 +209,11 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
             }
         }
         lds_barrier();
+        BD_CSTAMP(3);
         float hn_keep[4] = {0.f, 0.f, 0.f, 0.f}, g_keep[4][4];
-        const int my_nb = c + wave * C;                      // wave bi reduces block bi
-        const bool reducer = wave < kLocalBlocks && my_nb < Nb;
         if (reducer) {
             const int col = my_nb * 16 + (lane & 15);
             const bool okc = col < a.Be;
-            const float br = okc ? a.b_ih[col] + a.b_hh[col] : 0.f;
-            const float bz = okc ? a.b_ih[a.Be + col] + a.b_hh[a.Be + col] : 0.f;
-            const float bni = okc ? a.b_ih[2 * a.Be + col] : 0.f;
-            const float bnh = okc ? a.b_hh[2 * a.Be + col] : 0.f;
             floatx4 R = floatx4{br, br, br, br}, Z = floatx4{bz, bz, bz, bz};
             floatx4 NI = floatx4{bni, bni, bni, bni}, NH = floatx4{bnh, bnh, bnh, bnh};
             for (int w = 0; w < kWaves; ++w) {
@@ -213,7 +233,9 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
                 g_keep[r][0] = rr; g_keep[r][1] = zz; g_keep[r][2] = nn; g_keep[r][3] = NH[r];
             }
         }
+        BD_CSTAMP(4);
         publish(flags + c, (unsigned)(t + 1));
+        BD_CSTAMP(5);
         if (reducer) {                                        // plain stores after the flag: they do not delay it
             const int col = my_nb * 16 + (lane & 15);
 #pragma unroll
@@ -228,47 +250,80 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
                 }
             }
         }
+        BD_CSTAMP(6);
         wait_all(flags, C, (unsigned)(t + 1), err);
+        BD_CSTAMP(7);
         gather_payload(xbuf + (size_t)(t & 1) * nh, h_nxt, nh);
         lds_barrier();
+        BD_CSTAMP(8);
         // ---- D: posterior hidden (every member, full width) ----
-        tile_linear<1, kNI>(h_nxt, d.Kb_h, a.w_q1h, a.b_q1, a.Hd, [&](int, int nb, floatx4 acc) {
-            const int col = nb * 16 + (lane & 15);
+        {
+            const Seg segs[1] = {{h_nxt, a.w_q1h, d.Kb_h}};
+            tile_linear_pre<1, 1>(
+                segs, a.b_q1, a.Hd,
+                [&](int, int nb) {           // hoisted embedding projection: fetched before the contraction
+                    Pre4 p;
+                    const int col = nb * 16 + (lane & 15);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int grow = row0 + 4 * (lane >> 4) + r;
-                const bool ok = grow < a.B && col < a.Hd;
-                const float v = ok ? elu(acc[r] + a.pre_emb[(tb + grow) * a.Hd + col]) : 0.f;
-                qf[acc_frag_off(nb, lane, r)] = v;
-                if (lead && ok && a.sv_q) a.sv_q[(tb + grow) * a.Hd + col] = v;
-            }
-        });
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = row0 + 4 * (lane >> 4) + r;
+                        p.v[r] = (grow < a.B && col < a.Hd) ? a.pre_emb[(tb + grow) * a.Hd + col] : 0.f;
+                    }
+                    return p;
+                },
+                [&](int, int nb, floatx4 acc, const Pre4& p) {
+                    const int col = nb * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = row0 + 4 * (lane >> 4) + r;
+                        const bool ok = grow < a.B && col < a.Hd;
+                        const float v = ok ? elu(acc[r] + p.v[r]) : 0.f;
+                        qf[acc_frag_off(nb, lane, r)] = v;
+                        if (lead && ok && a.sv_q) a.sv_q[(tb + grow) * a.Hd + col] = v;
+                    }
+                });
+        }
         lds_barrier();
+        BD_CSTAMP(9);
         // ---- E: posterior mean / std / sample (every member; split-K over waves) ----
         {
             const Seg2 segs[1] = {{qf, a.w_q2m, a.w_q2s, d.Kb_hd}};
-            tile_linear_dual<1>(segs, a.b_q2, a.b_q2 + a.S, a.S, [&](int nb, floatx4 Mn, floatx4 Rw) {
-                const int col = nb * 16 + (lane & 15);
+            tile_linear_dual_pre<1>(
+                segs, a.b_q2, a.b_q2 + a.S, a.S,
+                [&](int nb) {                 // posterior noise: fetched before the contraction
+                    Pre4 p;
+                    const int col = nb * 16 + (lane & 15);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * (lane >> 4) + r, grow = row0 + row;
-                    if (col >= a.S) continue;
-                    float st = 0.f;
-                    if (grow < a.B) {
-                        const size_t i = (tb + grow) * a.S + col;
-                        const float sd = softplusf(Rw[r]) + a.min_std;
-                        st = Mn[r] + sd * a.eps_post[i];
-                        if (lead) {
-                            a.post_mean[i] = Mn[r];
-                            a.post_std[i] = sd;
-                            a.feat[(tb + grow) * F + a.Be + col] = st;
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = row0 + 4 * (lane >> 4) + r;
+                        p.v[r] = (grow < a.B && col < a.S) ? a.eps_post[(tb + grow) * a.S + col] : 0.f;
                     }
-                    s_plain[row * a.S + col] = st;
-                }
-            }, scratch);
+                    return p;
+                },
+                [&](int nb, floatx4 Mn, floatx4 Rw, const Pre4& p) {
+                    const int col = nb * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 4 * (lane >> 4) + r, grow = row0 + row;
+                        if (col >= a.S) continue;
+                        float st = 0.f;
+                        if (grow < a.B) {
+                            const size_t i = (tb + grow) * a.S + col;
+                            const float sd = softplusf(Rw[r]) + a.min_std;
+                            st = Mn[r] + sd * p.v[r];
+                            if (lead) {
+                                a.post_mean[i] = Mn[r];
+                                a.post_std[i] = sd;
+                                a.feat[(tb + grow) * F + a.Be + col] = st;
+                            }
+                        }
+                        s_plain[row * a.S + col] = st;
+                    }
+                },
+                scratch);
         }
         lds_barrier();
+        BD_CSTAMP(10);
         float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
     }
 }
@@ -334,55 +389,98 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
         // ---- 2: d q (every member) ----
         {
             const Seg segs[2] = {{dM, a.wt_q2m, d.Kb_s}, {dRaw, a.wt_q2s, d.Kb_s}};
-            tile_linear_seg<kNI, 2>(segs, nullptr, a.Hd, [&](int nb, floatx4 acc) {
-                const int col = nb * 16 + (lane & 15);
+            tile_linear_pre<1, 2>(
+                segs, nullptr, a.Hd,
+                [&](int, int nb) {
+                    Pre4 p;
+                    const int col = nb * 16 + (lane & 15);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int grow = row0 + 4 * (lane >> 4) + r;
-                    float v = 0.f;
-                    if (grow < a.B && col < a.Hd) {
-                        v = acc[r] * elu_grad_from_out(a.sv_q[(tb + grow) * a.Hd + col]);
-                        if (lead) a.d_q1_pre[(tb + grow) * a.Hd + col] = v;
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = row0 + 4 * (lane >> 4) + r;
+                        p.v[r] = (grow < a.B && col < a.Hd) ? a.sv_q[(tb + grow) * a.Hd + col] : 1.f;
                     }
-                    dQ[acc_frag_off(nb, lane, r)] = v;
-                }
-            });
+                    return p;
+                },
+                [&](int, int nb, floatx4 acc, const Pre4& p) {
+                    const int col = nb * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = row0 + 4 * (lane >> 4) + r;
+                        float v = 0.f;
+                        if (grow < a.B && col < a.Hd) {
+                            v = acc[r] * elu_grad_from_out(p.v[r]);
+                            if (lead) a.d_q1_pre[(tb + grow) * a.Hd + col] = v;
+                        }
+                        dQ[acc_frag_off(nb, lane, r)] = v;
+                    }
+                });
         }
         lds_barrier();
         // ---- 3: total d belief_{t+1}, GRU gate gradients (every member, full width) ----
-        tile_linear<1, kNI>(dQ, d.Kb_hd, a.wt_q1h, nullptr, a.Be, [&](int, int nb, floatx4 acc) {
-            const int col = nb * 16 + (lane & 15);
+        {
+            const Seg segs3[1] = {{dQ, a.wt_q1h, d.Kb_hd}};
+            tile_linear_pre<1, 1>(
+                segs3, nullptr, a.Be,
+                [&](int, int nb) {           // saved gates, previous belief, head gradients: before the contraction
+                    PreGate p;
+                    const int col = nb * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = row0 + 4 * (lane >> 4) + r;
+                        const bool ok = grow < a.B && col < a.Be;
+                        const float* g = a.sv_gates + (tb + grow) * 4 * a.Be + col;
+                        p.r[r] = ok ? g[0] : 0.f;
+                        p.z[r] = ok ? g[a.Be] : 0.f;
+                        p.n[r] = ok ? g[2 * a.Be] : 0.f;
+                        p.hn[r] = ok ? g[3 * a.Be] : 0.f;
+                        p.hprev[r] = !ok ? 0.f : (t > 0 ? a.feat[(tb - a.B + grow) * F + col]
+                                                        : a.init_belief[(size_t)grow * a.Be + col]);
+                        p.dfeat[r] = ok ? a.dfeat[(tb + grow) * F + col] : 0.f;
+                    }
+                    return p;
+                },
+                [&](int, int nb, floatx4 acc, const PreGate& p) {
+                    const int col = nb * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = row0 + 4 * (lane >> 4) + r;
+                        const int off = acc_frag_off(nb, lane, r);
+                        float vr = 0.f, vz = 0.f, vni = 0.f, vnh = 0.f, carry = 0.f;
+                        if (grow < a.B && col < a.Be) {
+                            const float dh = acc[r] + dhc[off] + p.dfeat[r];
+                            const float rr = p.r[r], zz = p.z[r], nn = p.n[r], hn = p.hn[r];
+                            const float dn = dh * (1.f - zz);
+                            const float dz = dh * (p.hprev[r] - nn);
+                            vni = dn * (1.f - nn * nn);
+                            vnh = vni * rr;
+                            vr = vni * hn * rr * (1.f - rr);
+                            vz = dz * zz * (1.f - zz);
+                            carry = dh * zz;
+                            if (lead) {
+                                float* gi = a.d_gi + (tb + grow) * 3 * a.Be + col;
+                                float* gh = a.d_gh + (tb + grow) * 3 * a.Be + col;
+                                gi[0] = vr; gi[a.Be] = vz; gi[2 * a.Be] = vni;
+                                gh[0] = vr; gh[a.Be] = vz; gh[2 * a.Be] = vnh;
+                            }
+                        }
+                        dR[off] = vr; dZ[off] = vz; dNI[off] = vni; dNH[off] = vnh;
+                        dhc[off] = carry;      // direct path dh*z; phase 4 adds W_hh^T terms for this member's blocks
+                    }
+                });
+        }
+        lds_barrier();
+        // ---- 4: through W_ih / W_hh: this member's column blocks, K split over the waves ----
+        const int my_nb = c + wave * C;
+        const bool reducer = wave < kLocalBlocks && my_nb < Nb;
+        float svx[4] = {1.f, 1.f, 1.f, 1.f};          // reducer's saved embed outputs: in flight before the contraction
+        if (reducer) {
+            const int col = my_nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int grow = row0 + 4 * (lane >> 4) + r;
-                const int off = acc_frag_off(nb, lane, r);
-                float vr = 0.f, vz = 0.f, vni = 0.f, vnh = 0.f, carry = 0.f;
-                if (grow < a.B && col < a.Be) {
-                    const float dh = acc[r] + dhc[off] + a.dfeat[(tb + grow) * F + col];
-                    const float* g = a.sv_gates + (tb + grow) * 4 * a.Be + col;
-                    const float rr = g[0], zz = g[a.Be], nn = g[2 * a.Be], hn = g[3 * a.Be];
-                    const float hprev = t > 0 ? a.feat[(tb - a.B + grow) * F + col]
-                                              : a.init_belief[(size_t)grow * a.Be + col];
-                    const float dn = dh * (1.f - zz);
-                    const float dz = dh * (hprev - nn);
-                    vni = dn * (1.f - nn * nn);
-                    vnh = vni * rr;
-                    vr = vni * hn * rr * (1.f - rr);
-                    vz = dz * zz * (1.f - zz);
-                    carry = dh * zz;
-                    if (lead) {
-                        float* gi = a.d_gi + (tb + grow) * 3 * a.Be + col;
-                        float* gh = a.d_gh + (tb + grow) * 3 * a.Be + col;
-                        gi[0] = vr; gi[a.Be] = vz; gi[2 * a.Be] = vni;
-                        gh[0] = vr; gh[a.Be] = vz; gh[2 * a.Be] = vnh;
-                    }
-                }
-                dR[off] = vr; dZ[off] = vz; dNI[off] = vni; dNH[off] = vnh;
-                dhc[off] = carry;          // direct path dh*z; phase 4 adds W_hh^T terms for this member's blocks
+                if (grow < a.B && col < a.Be) svx[r] = a.sv_x[(tb + grow) * a.Be + col];
             }
-        });
-        lds_barrier();
-        // ---- 4: through W_ih / W_hh: this member's column blocks, K split over the waves ----
+        }
         {
             const floatx4* __restrict__ R4 = reinterpret_cast<const floatx4*>(dR) + lane;
             const floatx4* __restrict__ Z4 = reinterpret_cast<const floatx4*>(dZ) + lane;
@@ -420,8 +518,6 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
             }
         }
         lds_barrier();
-        const int my_nb = c + wave * C;
-        const bool reducer = wave < kLocalBlocks && my_nb < Nb;
         float de_keep[4] = {0.f, 0.f, 0.f, 0.f};
         if (reducer) {
             floatx4 DX = floatx4{0.f, 0.f, 0.f, 0.f}, DH = DX;
@@ -437,7 +533,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
                 const int off = acc_frag_off(my_nb, lane, r);
                 float de = 0.f, carry = 0.f;
                 if (grow < a.B && col < a.Be) {
-                    de = DX[r] * elu_grad_from_out(a.sv_x[(tb + grow) * a.Be + col]);
+                    de = DX[r] * elu_grad_from_out(svx[r]);
                     carry = dhc[off] + DH[r];
                 }
                 st_sc1(xb + off, carry);            // payload = [dhc | dE], fragment order, as the LDS layout
@@ -494,6 +590,12 @@ static size_t scratch_floats_bwd() {
 
 extern "C" {
 using namespace bd;
+
+#ifdef BD_STAMPS
+int bd_debug_cstamps(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_cstamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int bd_observe_cluster_size(int Be) { return pick_cluster(Be); }
 

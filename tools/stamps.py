@@ -29,3 +29,19 @@ print(f"one imagination step of workgroup {os.environ.get('BD_STAMP_WG', 0)}: {t
 for i, n in enumerate(names):
     dt = st[i + 1] - st[i]
     print(f"  {n:28s} {dt:8d} ticks  {100.0 * dt / tot:5.1f} %")
+
+# ---- cluster observe scan (forward), member 0 of tile 0, step 5 ----
+fn2 = getattr(_cabi.lib, "bd_debug_cstamps", None)
+if fn2 is not None:
+    fn2.restype = ctypes.c_int
+    out2 = (ctypes.c_ulonglong * 64)()
+    assert fn2(out2) == 0
+    st = np.array(out2[:11], dtype=np.int64)
+    names = ["A masked state/action", "B embed (full)", "C GRU blocks, split-K", "reduce + gate math + sc1 stores",
+             "publish (vmcnt0+barrier+flag)", "plain stores", "wait_all", "gather payload", "D posterior hidden (full)",
+             "E posterior out (split-K)"]
+    tot = st[10] - st[0]
+    print(f"one observe step (cluster fwd, member 0): {tot} cycles")
+    for i, n in enumerate(names):
+        dt = st[i + 1] - st[i]
+        print(f"  {n:34s} {dt:8d}  {100.0 * dt / tot:5.1f} %")
