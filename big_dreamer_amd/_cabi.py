@@ -51,6 +51,13 @@ class MlpBwdArgs(C.Structure):
                 ("din1", P), ("ld1", I32), ("w1", I32), ("accumulate", I32)]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [("dpre", P), ("ldp", I32), ("act1", P), ("lda1", I32), ("M1", I32), ("act2", P), ("lda2", I32),
+                ("M", I32), ("N", I32), ("K", I32), ("dW", P), ("ldw", I32), ("db", P),
+                ("splits", I32), ("rows_per", I32), ("tiles_n", I32), ("tiles_k", I32), ("block_begin", I32),
+                ("red_begin", I32), ("ws_off", C.c_ulonglong)]
+
+
 def _ptr_fields(names):
     return [(n, P) for n in names]
 
@@ -100,6 +107,8 @@ _SIGS = {
     "bd_mlp_backward": (I32, [C.POINTER(MlpBwdArgs), P]),
     "bd_wgrad_ws_floats": (C.c_size_t, [I32, I32, I32]),
     "bd_wgrad": (I32, [P, I32, P, I32, I32, I32, I32, P, I32, P, I32, P, C.c_size_t, P]),
+    "bd_wgrad_plan": (I32, [C.POINTER(WgradDesc), I32, C.POINTER(I32), C.POINTER(I32), C.POINTER(C.c_size_t)]),
+    "bd_wgrad_grouped": (I32, [P, I32, I32, I32, P, P]),
     "bd_observe_forward": (I32, [C.POINTER(ObserveFwdArgs), P]),
     "bd_observe_backward": (I32, [C.POINTER(ObserveBwdArgs), P]),
     "bd_observe_cluster_size": (I32, [I32]),

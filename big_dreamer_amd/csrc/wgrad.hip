@@ -76,6 +76,94 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// ---- grouped form: all weight-gradient GEMMs of one backward pass in ONE launch -----------------------------
+// A train step needs 36 of these GEMMs (68 parameter tensors); as separate launches most are latency-bound
+// (M = 2450 rows, 60..600 x 3..1024 outputs) and the launch/reduce pairs alone cost ~1.3 ms per step.  The grouped
+// kernel walks a descriptor table in HBM: blockIdx.x -> (GEMM, output tile, row split); the grouped reduce sums the
+// slabs of every GEMM in fixed order.  A descriptor may take its activations from two sources split at row M1
+// (rows whose "previous belief" is the initial state / whose actor input is the start feature), which replaces the
+// accumulate pass of the ungrouped form.
+__global__ __launch_bounds__(kThreads) void wgrad_grouped_kernel(const bd_wgrad_desc* __restrict__ descs, int n,
+                                                                 float* __restrict__ ws) {
+    __shared__ float P[kWM][kWT];
+    __shared__ float A[kWM][kWT];
+    int g = 0;
+    while (g + 1 < n && (int)blockIdx.x >= descs[g + 1].block_begin) ++g;     // uniform scan, n is small
+    const bd_wgrad_desc d = descs[g];
+    const int hb = d.db != nullptr;
+    const int Kext = d.K + hb;
+    int local = blockIdx.x - d.block_begin;
+    const int z = local / (d.tiles_n * d.tiles_k);
+    local -= z * d.tiles_n * d.tiles_k;
+    const int n0 = (local / d.tiles_k) * kWT, k0 = (local % d.tiles_k) * kWT;
+    const int m_begin = z * d.rows_per;
+    const int m_end = min(d.M, m_begin + d.rows_per);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;
+    floatx16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    float pv[kWM / 4], av[kWM / 4];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < kWM / 4; ++i) {
+            const int m = m0 + r0 + 4 * i;
+            const bool ok = m < m_end;
+            pv[i] = (ok && n0 + c < d.N) ? d.dpre[(size_t)m * d.ldp + n0 + c] : 0.f;
+            const int k = k0 + c;
+            float v = 0.f;
+            if (ok) {
+                if (k < d.K) v = m < d.M1 ? d.act1[(size_t)m * d.lda1 + k] : d.act2[(size_t)(m - d.M1) * d.lda2 + k];
+                else if (k == d.K && hb) v = 1.f;
+            }
+            av[i] = v;
+        }
+    };
+    fetch(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += kWM) {
+        __syncthreads();   // previous stage's LDS reads are done
+#pragma unroll
+        for (int i = 0; i < kWM / 4; ++i) {
+            P[r0 + 4 * i][c] = pv[i];
+            A[r0 + 4 * i][c] = av[i];
+        }
+        __syncthreads();
+        if (m0 + kWM < m_end) fetch(m0 + kWM);      // next chunk's global loads fly under this chunk's MFMAs
+#pragma unroll
+        for (int s = 0; s < kWM / 2; ++s) {
+            const float a = P[2 * s + (lane >> 5)][wn + (lane & 31)];
+            const float b = A[2 * s + (lane >> 5)][wk + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    float* slab = ws + d.ws_off + (size_t)z * d.N * Kext;
+    const int k = k0 + wk + (lane & 31);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int nn = n0 + wn + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (nn < d.N && k < Kext) slab[(size_t)nn * Kext + k] = acc[reg];
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(const bd_wgrad_desc* __restrict__ descs, int n,
+                                                                   const float* __restrict__ ws) {
+    int g = 0;
+    while (g + 1 < n && (int)blockIdx.x >= descs[g + 1].red_begin) ++g;
+    const bd_wgrad_desc d = descs[g];
+    const int hb = d.db != nullptr;
+    const int Kext = d.K + hb;
+    const int total = d.N * Kext;
+    const int e = (blockIdx.x - d.red_begin) * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const float* p = ws + d.ws_off + e;
+    float s = 0.f;
+    for (int z = 0; z < d.splits; ++z) s += p[(size_t)z * total];
+    const int nn = e / Kext, k = e - nn * Kext;
+    if (k < d.K) d.dW[(size_t)nn * d.ldw + k] = s;
+    else d.db[nn] = s;
+}
+
 static void wgrad_plan(int M, int N, int K, int has_bias, int* splits, int* rows_per) {
     const int tiles = cdiv(N, kWT) * cdiv(K + has_bias, kWT);
     int s = 1024 / tiles;
@@ -90,6 +178,52 @@ static void wgrad_plan(int M, int N, int K, int has_bias, int* splits, int* rows
 }  // namespace bd
 
 extern "C" {
+
+int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red_blocks, size_t* ws_floats) {
+    using namespace bd;
+    BD_REQUIRE(descs && n > 0 && total_blocks && total_red_blocks && ws_floats, "bd_wgrad_plan: bad arguments");
+    int blocks = 0, red = 0;
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        bd_wgrad_desc& d = descs[i];
+        BD_REQUIRE(d.dpre && d.act1 && d.dW && d.M > 0 && d.N > 0 && d.K > 0 && d.M1 >= 0 && d.M1 <= d.M,
+                   "bd_wgrad_plan: descriptor %d is malformed", i);
+        BD_REQUIRE(d.M1 == d.M || d.act2, "bd_wgrad_plan: descriptor %d needs a second activation source", i);
+        BD_REQUIRE(d.ldp >= d.N && d.lda1 >= d.K && d.ldw >= d.K && (d.M1 == d.M || d.lda2 >= d.K),
+                   "bd_wgrad_plan: descriptor %d has a leading dimension that is too small", i);
+        const int hb = d.db != nullptr;
+        d.tiles_n = cdiv(d.N, kWT);
+        d.tiles_k = cdiv(d.K + hb, kWT);
+        int s = d.M / 512;                      // ~512 rows (16 LDS stages) per workgroup
+        if (s < 1) s = 1;
+        if (s > 64) s = 64;
+        d.rows_per = cdiv(cdiv(d.M, s), kWM) * kWM;
+        d.splits = cdiv(d.M, d.rows_per);
+        d.block_begin = blocks;
+        d.red_begin = red;
+        d.ws_off = off;
+        blocks += d.tiles_n * d.tiles_k * d.splits;
+        red += cdiv(d.N * (d.K + hb), 256);
+        off += (size_t)d.splits * d.N * (d.K + hb);
+    }
+    *total_blocks = blocks;
+    *total_red_blocks = red;
+    *ws_floats = off;
+    return 0;
+}
+
+int bd_wgrad_grouped(const bd_wgrad_desc* descs_dev, int n, int total_blocks, int total_red_blocks, float* ws,
+                     void* stream) {
+    using namespace bd;
+    BD_REQUIRE(descs_dev && ws && n > 0 && n <= 4096 && total_blocks > 0 && total_red_blocks > 0,
+               "bd_wgrad_grouped: bad arguments");
+    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(total_blocks), dim3(kThreads), 0, (hipStream_t)stream, descs_dev, n, ws);
+    BD_CHECK_LAUNCH("bd_wgrad_grouped");
+    hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3(total_red_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n,
+                       ws);
+    BD_CHECK_LAUNCH("bd_wgrad_grouped(reduce)");
+    return 0;
+}
 
 size_t bd_wgrad_ws_floats(int M, int N, int K) {
     // the split count depends on whether the bias column is appended: cover both forms

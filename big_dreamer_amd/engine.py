@@ -66,6 +66,42 @@ class ParamGroup:
             off += k
 
 
+class WgradBatch:
+    """All weight-gradient GEMMs of one backward pass -> one bd_wgrad_grouped launch (+ one grouped reduce).
+    The descriptor table lives in HBM and is rebuilt only when a buffer pointer or size changes."""
+
+    def __init__(self, eng: "DreamerEngine", name: str):
+        self.eng, self.name = eng, name
+        self.items: List[tuple] = []
+        self._key = None
+        self._table = None
+        self._plan = (0, 0)
+
+    def add(self, dpre, ldp, act, lda, M, N, K, dW, ldw, db=None, act2=None, lda2=0, M1=None) -> None:
+        self.items.append((ptr(dpre), ldp, ptr(act), lda, M if M1 is None else M1, ptr(act2), lda2, M, N, K, ptr(dW), ldw,
+                           ptr(db)))
+
+    def run(self) -> None:
+        eng = self.eng
+        key = tuple(self.items)
+        if key != self._key:
+            n = len(self.items)
+            descs = (cabi.WgradDesc * n)()
+            for i, it in enumerate(self.items):
+                (descs[i].dpre, descs[i].ldp, descs[i].act1, descs[i].lda1, descs[i].M1, descs[i].act2, descs[i].lda2,
+                 descs[i].M, descs[i].N, descs[i].K, descs[i].dW, descs[i].ldw, descs[i].db) = it
+            tb, tr, wsf = C.c_int(0), C.c_int(0), C.c_size_t(0)
+            cabi.check(lib.bd_wgrad_plan(descs, n, C.byref(tb), C.byref(tr), C.byref(wsf)))
+            self._table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(eng.dev)
+            self._plan = (n, tb.value, tr.value)
+            if eng._wgrad_ws.numel() < wsf.value:
+                eng._wgrad_ws = torch.zeros(wsf.value, dtype=torch.float32, device=eng.dev)
+            self._key = key
+        n, tb, tr = self._plan
+        cabi.check(lib.bd_wgrad_grouped(self._table.data_ptr(), n, tb, tr, ptr(eng._wgrad_ws), cabi.stream()))
+        self.items = []
+
+
 class DreamerEngine:
     def __init__(self, dims: Dims, hp: Optional[dict] = None, device="cuda", params: Optional[dict] = None,
                  world_size: int = 1, process_group=None):
@@ -94,6 +130,7 @@ class DreamerEngine:
         self.scalars = torch.zeros(N_SLOTS, dtype=torch.float32, device=self.dev)
         self.red_ws = torch.zeros(int(lib.bd_reduce_ws_floats()), dtype=torch.float32, device=self.dev)
         self._wgrad_ws = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self._wbatch = {k: WgradBatch(self, k) for k in ("model", "actor", "critic")}
         self._buf: Dict[str, torch.Tensor] = {}
         # cluster variant of the observe scan (several CUs per 16-row tile): on unless BD_OBS_CLUSTER=0
         self.use_obs_cluster = os.environ.get("BD_OBS_CLUSTER", "1") != "0" and int(lib.bd_observe_cluster_size(d.Be)) > 0
@@ -261,12 +298,12 @@ class DreamerEngine:
         cabi.check(lib.bd_wgrad(ptr(dpre), ldp, ptr(act), lda, M, N, K, ptr(dW), ldw, ptr(db), int(accumulate),
                                 ptr(self._wgrad_ws), self._wgrad_ws.numel(), cabi.stream()))
 
-    def _dense_wgrads(self, mod: str, M: int, dpres, inp, ld_in, saves, sizes) -> None:
-        """Weight/bias gradients of a DenseModel from its pre-activation gradients."""
+    def _dense_wgrads(self, batch: "WgradBatch", mod: str, M: int, dpres, inp, ld_in, saves, sizes) -> None:
+        """Weight/bias gradients of a DenseModel from its pre-activation gradients (queued on `batch`)."""
         for l in range(len(sizes) - 1):
             act, lda = (inp, ld_in) if l == 0 else (saves[l - 1], sizes[l])
-            self.wgrad(dpres[l], sizes[l + 1], act, lda, M, sizes[l + 1], sizes[l],
-                       self.G(mod, f"model.{2 * l}.weight"), sizes[l], self.G(mod, f"model.{2 * l}.bias"))
+            batch.add(dpres[l], sizes[l + 1], act, lda, M, sizes[l + 1], sizes[l],
+                      self.G(mod, f"model.{2 * l}.weight"), sizes[l], self.G(mod, f"model.{2 * l}.bias"))
 
     def _allreduce(self, t: torch.Tensor) -> None:
         self.dp.allreduce_sum_(t)
@@ -504,28 +541,30 @@ class DreamerEngine:
         enc_dpre = [self.buf(f"enc_dpre{l}", N, d.Hd) for l in range(DENSE_LAYERS)] + [self.buf("d_emb", N, d.E)]
         self.mlp_backward(N, d_q1, d.Hd, enc_layers, enc_acts + [None, None], enc_dpre + [None])
 
-        # ---- weight gradients (into the flat model gradient buffer) ----
+        # ---- weight gradients (into the flat model gradient buffer): one grouped launch ----
         Gt = lambda n: self.G("transition_model", n)
-        self.wgrad(d_gi, 3 * d.Be, self._buf["sv_x"], d.Be, N, 3 * d.Be, d.Be, Gt("rnn.weight_ih"), d.Be, Gt("rnn.bias_ih"))
-        self.wgrad(d_gh, 3 * d.Be, init_belief, d.Be, B, 3 * d.Be, d.Be, Gt("rnn.weight_hh"), d.Be, Gt("rnn.bias_hh"))
-        if T > 1:   # previous belief of step t >= 1 is the belief part of feat[t-1]
-            self.wgrad(d_gh[B:], 3 * d.Be, feat, F, N - B, 3 * d.Be, d.Be, Gt("rnn.weight_hh"), d.Be, Gt("rnn.bias_hh"),
-                       accumulate=True)
+        wb = self._wbatch["model"]
+        wb.add(d_gi, 3 * d.Be, self._buf["sv_x"], d.Be, N, 3 * d.Be, d.Be, Gt("rnn.weight_ih"), d.Be, Gt("rnn.bias_ih"))
+        # previous belief: the initial belief for step 0 (rows < B), the belief part of feat[t-1] afterwards
+        wb.add(d_gh, 3 * d.Be, init_belief, d.Be, N, 3 * d.Be, d.Be, Gt("rnn.weight_hh"), d.Be, Gt("rnn.bias_hh"),
+               act2=feat, lda2=F, M1=B)
         gWe = Gt("fc_embed_state_action.0.weight")
-        self.wgrad(d_e, d.Be, self._buf["sv_s"], d.S, N, d.Be, d.S, gWe, d.S + d.A, Gt("fc_embed_state_action.0.bias"))
-        self.wgrad(d_e, d.Be, actions[:-1], d.A, N, d.Be, d.A, gWe[:, d.S:], d.S + d.A)
-        self.wgrad(d_p_hid, d.Hd, feat, F, N, d.Hd, d.Be, Gt("belief_prior.model.0.weight"), d.Be, Gt("belief_prior.model.0.bias"))
-        self.wgrad(d_p_out, 2 * d.S, p_hid, d.Hd, N, 2 * d.S, d.Hd, Gt("belief_prior.model.2.weight"), d.Hd,
-                   Gt("belief_prior.model.2.bias"))
+        wb.add(d_e, d.Be, self._buf["sv_s"], d.S, N, d.Be, d.S, gWe, d.S + d.A, Gt("fc_embed_state_action.0.bias"))
+        wb.add(d_e, d.Be, actions[:-1], d.A, N, d.Be, d.A, gWe[:, d.S:], d.S + d.A)
+        wb.add(d_p_hid, d.Hd, feat, F, N, d.Hd, d.Be, Gt("belief_prior.model.0.weight"), d.Be, Gt("belief_prior.model.0.bias"))
+        wb.add(d_p_out, 2 * d.S, p_hid, d.Hd, N, 2 * d.S, d.Hd, Gt("belief_prior.model.2.weight"), d.Hd,
+               Gt("belief_prior.model.2.bias"))
         gWq1 = Gt("belief_posterior.model.0.weight")
-        self.wgrad(d_q1, d.Hd, feat, F, N, d.Hd, d.Be, gWq1, d.Be + d.E, Gt("belief_posterior.model.0.bias"))
-        self.wgrad(d_q1, d.Hd, emb, d.E, N, d.Hd, d.E, gWq1[:, d.Be:], d.Be + d.E)
-        self.wgrad(d_q2, 2 * d.S, self._buf["sv_q"], d.Hd, N, 2 * d.S, d.Hd, Gt("belief_posterior.model.2.weight"), d.Hd,
-                   Gt("belief_posterior.model.2.bias"))
+        wb.add(d_q1, d.Hd, feat, F, N, d.Hd, d.Be, gWq1, d.Be + d.E, Gt("belief_posterior.model.0.bias"))
+        wb.add(d_q1, d.Hd, emb, d.E, N, d.Hd, d.E, gWq1[:, d.Be:], d.Be + d.E)
+        wb.add(d_q2, 2 * d.S, self._buf["sv_q"], d.Hd, N, 2 * d.S, d.Hd, Gt("belief_posterior.model.2.weight"), d.Hd,
+               Gt("belief_posterior.model.2.bias"))
         dense_sizes = lambda i, o: [i] + [d.Hd] * DENSE_LAYERS + [o]
-        self._dense_wgrads("observation_model", N, om_dpre, feat, F, om_acts, dense_sizes(F, d.O))
-        self._dense_wgrads("reward_model", N, rw_dpre, feat, F, rw_acts, dense_sizes(F, 1))
-        self._dense_wgrads("encoder", N, enc_dpre, obs_t, d.O, enc_acts, dense_sizes(d.O, d.E))
+        self._dense_wgrads(wb, "observation_model", N, om_dpre, feat, F, om_acts, dense_sizes(F, d.O))
+        self._dense_wgrads(wb, "reward_model", N, rw_dpre, feat, F, rw_acts, dense_sizes(F, 1))
+        self._dense_wgrads(wb, "encoder", N, enc_dpre, obs_t, d.O, enc_acts, dense_sizes(d.O, d.E))
+        with self.span("wgrad_model"):
+            wb.run()
         with self.span("opt_model"):
             self.optimizer_step("model", SLOT_GN_MODEL, hp["model_learning_rate"])
 
@@ -568,16 +607,16 @@ class DreamerEngine:
         with self.span("imagine_bwd"):
             cabi.check(lib.bd_imagine_backward(C.byref(c), st))
         Ga = lambda n: self.G("actor", n)
-        # layer 0 input = [h_t; s_t]: start features for t = 0, imagined features of step t-1 afterwards
-        self.wgrad(d_apre[0], d.Hd, feat, F, N, d.Hd, F, Ga("model.0.weight"), F, Ga("model.0.bias"))
-        if Hm > 1:
-            self.wgrad(d_apre[0][N:], d.Hd, ifeat, F, Mi - N, d.Hd, F, Ga("model.0.weight"), F, Ga("model.0.bias"),
-                       accumulate=True)
+        wa = self._wbatch["actor"]
+        # layer 0 input = [h_t; s_t]: start features for t = 0 (rows < N), imagined features of step t-1 afterwards
+        wa.add(d_apre[0], d.Hd, feat, F, Mi, d.Hd, F, Ga("model.0.weight"), F, Ga("model.0.bias"), act2=ifeat, lda2=F, M1=N)
         for l in range(1, DENSE_LAYERS):
-            self.wgrad(d_apre[l], d.Hd, sv_actor[l - 1], d.Hd, Mi, d.Hd, d.Hd, Ga(f"model.{2 * l}.weight"), d.Hd,
-                       Ga(f"model.{2 * l}.bias"))
-        self.wgrad(d_aout, 2 * d.A, sv_actor[DENSE_LAYERS - 1], d.Hd, Mi, 2 * d.A, d.Hd,
-                   Ga(f"model.{2 * DENSE_LAYERS}.weight"), d.Hd, Ga(f"model.{2 * DENSE_LAYERS}.bias"))
+            wa.add(d_apre[l], d.Hd, sv_actor[l - 1], d.Hd, Mi, d.Hd, d.Hd, Ga(f"model.{2 * l}.weight"), d.Hd,
+                   Ga(f"model.{2 * l}.bias"))
+        wa.add(d_aout, 2 * d.A, sv_actor[DENSE_LAYERS - 1], d.Hd, Mi, 2 * d.A, d.Hd,
+               Ga(f"model.{2 * DENSE_LAYERS}.weight"), d.Hd, Ga(f"model.{2 * DENSE_LAYERS}.bias"))
+        with self.span("wgrad_actor"):
+            wa.run()
         with self.span("opt_actor"):
             self.optimizer_step("actor", SLOT_GN_ACTOR, hp["actor_learning_rate"])
 
@@ -587,7 +626,10 @@ class DreamerEngine:
         cabi.check(lib.bd_normal_nll(ptr(c_out), 1, ptr(returns), 1, Mi, 1, inv_mi, ptr(d_c), 1, sc, SLOT_VAL, ws, st))
         c_dpre = [self.buf(f"ic_dpre{l}", Mi, d.Hd) for l in range(DENSE_LAYERS)] + [d_c]
         self.mlp_backward(Mi, d_c, 1, c_layers, c_acts + [None], c_dpre[:-1] + [None])
-        self._dense_wgrads("critic", Mi, c_dpre, ifeat, F, c_acts, dense_sizes(F, 1))
+        wc = self._wbatch["critic"]
+        self._dense_wgrads(wc, "critic", Mi, c_dpre, ifeat, F, c_acts, dense_sizes(F, 1))
+        with self.span("wgrad_critic"):
+            wc.run()
         with self.span("opt_critic"):
             self.optimizer_step("critic", SLOT_GN_CRITIC, hp["value_learning_rate"])
 

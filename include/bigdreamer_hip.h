@@ -99,6 +99,25 @@ size_t bd_wgrad_ws_floats(int M, int N, int K);
 int bd_wgrad(const float* dpre, int ldp, const float* act, int lda, int M, int N, int K,
              float* dW, int ldw, float* db, int accumulate, float* ws, size_t ws_floats, void* stream);
 
+/* Grouped form: every weight-gradient GEMM of one backward pass in ONE launch (+ one grouped reduce).  Fill the
+ * caller fields of each descriptor on the host, let bd_wgrad_plan add the launch plan (and tell the slab workspace
+ * size), copy the table to device memory once, then call bd_wgrad_grouped every step.  Rows [0, M1) take their
+ * activations from act1, rows [M1, M) from act2[row - M1] (set M1 = M and act2 = NULL for a single source). */
+typedef struct {
+    const float* dpre; int ldp;               /* [M x N] pre-activation gradients                            */
+    const float* act1; int lda1; int M1;
+    const float* act2; int lda2;
+    int M, N, K;
+    float* dW; int ldw;                        /* [N x K] output                                              */
+    float* db;                                 /* [N] or NULL                                                 */
+    /* filled by bd_wgrad_plan */
+    int splits, rows_per, tiles_n, tiles_k, block_begin, red_begin;
+    unsigned long long ws_off;
+} bd_wgrad_desc;
+int bd_wgrad_plan(bd_wgrad_desc* descs_host, int n, int* total_blocks, int* total_red_blocks, size_t* ws_floats);
+int bd_wgrad_grouped(const bd_wgrad_desc* descs_dev, int n, int total_blocks, int total_red_blocks, float* ws,
+                     void* stream);
+
 /* ---- RSSM observe scan: TransitionModel.forward with embeddings (src/models.py:191-299) ------
  * One persistent launch walks all T steps; a workgroup owns 16 batch rows (rows are independent, so
  * there is no inter-workgroup synchronisation).  The prior head (src/models.py:256) does not feed the
