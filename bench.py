@@ -48,6 +48,17 @@ def algorithmic(d):
     return flops, step_bytes
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_traffic.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled for gfx950).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    t = json.load(open(files[-1])).get(kernel)
+    return (t["hbm_bytes_per_launch"], os.path.basename(files[-1])) if t else (None, None)
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -157,6 +168,7 @@ def main():
         flops, step_bytes = algorithmic(d)
         dom = max((k for k in kt if k in flops), key=lambda k: kt[k][0] * kt[k][1])
         ach = flops[dom] / (kt[dom][0] * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic(dom)
         out = {
             "metric": "latent transitions/sec (RSSM + imagination) at batch=50 chunk=50 H=15",
             "value": d.transitions_per_step * args.steps * world / dt,
@@ -169,12 +181,14 @@ def main():
                                    "hidden=200 embedding=1024 action=1 obs=3, batch=50/GPU chunk=50 H=15",
                        "global_batch": d.B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "avg_launch_ms": kt[dom][0], "launches": kt[dom][1],
                          "algorithmic_flop_per_launch": flops[dom]},
             "hbm_roofline_whole_step": {"achieved": step_bytes / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBPS,
                                         "unit": "GB/s", "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS,
                                         "algorithmic_bytes_per_step": step_bytes},
+            "kernel_tflops": {k: round(flops[k] / (kt[k][0] * 1e-3) / 1e12, 2) for k in flops if k in kt},
             "kernel_ms": {k: round(v[0], 4) for k, v in kt.items()},
             "losses": {k: round(v, 5) for k, v in logs.items()},
         }

@@ -3,6 +3,7 @@
 // bd_wgrad.  One workgroup = 16*RT rows; the whole chain runs out of LDS, weights stream from L2.
 #include "bd_device.h"
 #include "bd_host.h"
+#include <stdlib.h>
 
 namespace bd {
 
@@ -132,7 +133,10 @@ static int launch_chain(K kernel, const char* name, int M, int RT, int KbA, int 
 static int pick_rt(int M, int KbA, int KbB) {
     const int tiles = cdiv(M, 16);
     int rt = tiles >= 1024 ? 2 : 1;
-    while (rt > 1 && ((size_t)rt * (KbA + KbB) * kFragFloats + kSplitScratchFloats) * sizeof(float) > 64 * 1024) rt >>= 1;
+    static const char* force = getenv("BD_MLP_RT");          // tuning experiments only
+    if (force) rt = atoi(force) >= 2 && tiles >= 1024 ? 2 : 1;
+    const size_t cap = force ? 80 * 1024 : 64 * 1024;         // 2 workgroups per CU
+    while (rt > 1 && ((size_t)rt * (KbA + KbB) * kFragFloats + kSplitScratchFloats) * sizeof(float) > cap) rt >>= 1;
     return rt;
 }
 
