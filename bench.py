@@ -76,7 +76,7 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(d, budget_s=15.0, max_steps=8):
+def cpu_baseline(d, budget_s=15.0, max_steps=8):   # (pixel: ~8 s per step -> 1-2 steps)
     """Oracle (CPU restatement of the reference, parity-pinned) timed on this host's cores: reported only.
     Bounded sample: full train_steps until ~budget_s of CPU work (at least 1, at most max_steps)."""
     from big_dreamer_amd import synth
@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pixel", action="store_true",
+                    help="BASELINE.json configs[2] (64x64 pixel observations, action dim 17) instead of the default configs[1]")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,12 +124,14 @@ def main():
     from big_dreamer_amd.engine import DreamerEngine
     from big_dreamer_amd.memory import ExperienceReplay
 
-    d = synth.CONFIG2
+    d = synth.CONFIG3 if args.pixel else synth.CONFIG2
     np.random.seed(rank)
     torch.manual_seed(rank)
     eng = DreamerEngine(d, None, dev, params=synth.make_params(d, 0), world_size=world)
-    rep = synth.make_replay(d, rows=5000, seed=0)
-    buf = ExperienceReplay(5000, d.A, 5, False, d.O, dev)
+    rep = synth.make_replay(d if not args.pixel else synth.Dims(A=d.A, O=3), rows=5000, seed=0)
+    buf = ExperienceReplay(5000, d.A, 5, args.pixel, d.O, dev)
+    if args.pixel:      # uniform uint8 frames
+        rep["observations"] = np.random.default_rng(0).integers(0, 256, size=(5000, 3, 64, 64), dtype=np.uint8)
     for k, v in rep.items():
         getattr(buf, k)[:] = v
     buf.idx, buf.full = 0, True
@@ -177,8 +181,11 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: state-obs Dreamer train_step, belief=200 state=30 "
-                                   "hidden=200 embedding=1024 action=1 obs=3, batch=50/GPU chunk=50 H=15",
+            "config": {"workload": ("BASELINE.json configs[2]: 64x64 pixel-obs Dreamer train_step (conv stacks on MIOpen), "
+                                    "belief=200 state=30 hidden=200 embedding=1024 action=17, batch=50/GPU chunk=50 H=15")
+                       if args.pixel else
+                       ("BASELINE.json configs[1]: state-obs Dreamer train_step, belief=200 state=30 "
+                        "hidden=200 embedding=1024 action=1 obs=3, batch=50/GPU chunk=50 H=15"),
                        "global_batch": d.B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,

@@ -130,6 +130,7 @@ _SIGS = {
     "bd_adam_step": (I32, [P, P, P, P, C.c_size_t, F32, F32, F32, F32, F32, I32, F32, P, I32, P]),
     "bd_polyak": (I32, [P, P, C.c_size_t, F32, P]),
     "bd_replay_gather": (I32, [P, P, I32, I32, P, P]),
+    "bd_replay_gather_pixels": (I32, [P, P, I32, I32, I32, P, P, P]),
     "bd_reduce_ws_floats": (C.c_size_t, []),
 }
 
@@ -150,7 +151,7 @@ def ptr(t) -> int:
     """Device pointer of a tensor (None -> NULL)."""
     if t is None:
         return None
-    assert t.dtype in (torch.float32, torch.int64) and t.is_cuda, "expected a CUDA fp32/int64 tensor"
+    assert t.dtype in (torch.float32, torch.int64, torch.uint8) and t.is_cuda, "expected a CUDA fp32/int64/uint8 tensor"
     return t.data_ptr()
 
 

@@ -43,6 +43,28 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
         dst[e] = src[(size_t)idx[r] * width + c];
     }
 }
+// Pixel replay: gather uint8 frames by row index and undo the bit-depth quantisation in one pass
+// (ExperienceReplay._retrieve_batch + preprocess_observation_, src/memory.py:70-85, src/utils.py:299-317):
+//   out = floor(u8 / 2^(8-bits)) / 2^bits - 0.5 + noise / 2^bits        (noise ~ U[0,1), explicit input)
+// HBM-bound byte work: 4 pixels per thread (uchar4 in, float4 noise in, float4 out), fully coalesced.
+__global__ __launch_bounds__(256) void gather_pixels_kernel(const unsigned char* __restrict__ src,
+                                                            const int64_t* __restrict__ idx, int n_idx, int pixels,
+                                                            float inv_q, float inv_b, const float* __restrict__ noise,
+                                                            float* __restrict__ dst) {
+    const int quads = pixels >> 2;
+    const size_t total = (size_t)n_idx * quads;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / quads, q = e - r * quads;
+        const uchar4 u = reinterpret_cast<const uchar4*>(src + (size_t)idx[r] * pixels)[q];
+        const floatx4 nz = reinterpret_cast<const floatx4*>(noise)[e];
+        floatx4 o;
+        o[0] = floorf((float)u.x * inv_q) * inv_b - 0.5f + nz[0] * inv_b;
+        o[1] = floorf((float)u.y * inv_q) * inv_b - 0.5f + nz[1] * inv_b;
+        o[2] = floorf((float)u.z * inv_q) * inv_b - 0.5f + nz[2] * inv_b;
+        o[3] = floorf((float)u.w * inv_q) * inv_b - 0.5f + nz[3] * inv_b;
+        reinterpret_cast<floatx4*>(dst)[e] = o;
+    }
+}
 }  // namespace bd
 
 extern "C" {
@@ -65,6 +87,18 @@ int bd_replay_gather(const float* src, const int64_t* idx, int n_idx, int width,
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(bd::gather_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, idx, n_idx, width, dst);
     BD_CHECK_LAUNCH("bd_replay_gather");
+    return 0;
+}
+
+int bd_replay_gather_pixels(const unsigned char* src, const int64_t* idx, int n_idx, int pixels, int bit_depth,
+                            const float* noise, float* dst, void* stream) {
+    BD_REQUIRE(src && idx && noise && dst && n_idx > 0 && pixels > 0 && (pixels & 3) == 0 && bit_depth >= 1 && bit_depth <= 8,
+               "bd_replay_gather_pixels: bad arguments");
+    const size_t total = (size_t)n_idx * (pixels >> 2);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bd::gather_pixels_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, idx, n_idx, pixels,
+                       1.0f / (float)(1 << (8 - bit_depth)), 1.0f / (float)(1 << bit_depth), noise, dst);
+    BD_CHECK_LAUNCH("bd_replay_gather_pixels");
     return 0;
 }
 

@@ -16,7 +16,7 @@ from torch import Tensor
 from . import _cabi as cabi
 from .engine import DreamerEngine
 from .memory import ExperienceReplay
-from .models import ActorModel, DenseModel, TransitionModel, encoder_for
+from .models import ActorModel, CnnImageEncoder, DenseModel, ObservationModel, TransitionModel, encoder_for
 from .synth import Dims
 
 
@@ -35,8 +35,6 @@ class Dreamer:
 
     def __init__(self, params: Dict[str, Any], env, device: Optional[str] = None, world_size: int = 1,
                  process_group=None):
-        if params.get("pixel_observation", False):
-            raise NotImplementedError("pixel observations (conv encoder/decoder) are not in this build's scope yet")
         if params.get("latent_distribution", "Gaussian") != "Gaussian":
             raise NotImplementedError("Categorical latents: the reference path crashes at HEAD (parity unpinned)")
         if params["ActorCritic"]["gradient_mixing"] != -1:
@@ -57,10 +55,11 @@ class Dreamer:
         self.action_noise = params["action_noise"]
         self.action_repeat = params["action_repeat"]
         self.seed_steps = params["seed_steps"]
-        self.pixel_observation = False
+        self.pixel_observation = bool(params.get("pixel_observation", False))
+        obs_size = 3 * 64 * 64 if self.pixel_observation else env.observation_size
         self.dims = Dims(B=self.batch_size, L=self.seq_len, H=self.planning_horizon, Be=self.belief_size,
                          S=self.state_size, Hd=self.hidden_size, E=self.embedding_size, A=self.action_size,
-                         O=env.observation_size)
+                         O=obs_size, pixel=self.pixel_observation)
         self.engine = DreamerEngine(self.dims, _hp_from_params(params), self.device, world_size=world_size,
                                     process_group=process_group)
         e = self.engine
@@ -68,11 +67,14 @@ class Dreamer:
         # flat buffers), so seeding torch before construction reproduces a run (src/main.py:56-58).
         init = {}
         feat = self.belief_size + self.state_size
+        px, E = self.pixel_observation, self.embedding_size
         for mod, build in (
             ("transition_model", lambda: _ref_init_transition(self.dims)),
-            ("observation_model", lambda: _ref_init_dense(feat, self.hidden_size, env.observation_size)),
+            ("observation_model", (lambda: _ref_init_decoder(feat, E)) if px else
+             (lambda: _ref_init_dense(feat, self.hidden_size, env.observation_size))),
             ("reward_model", lambda: _ref_init_dense(feat, self.hidden_size, 1)),
-            ("encoder", lambda: _ref_init_dense(env.observation_size, self.hidden_size, self.embedding_size)),
+            ("encoder", (lambda: _ref_init_cnn(E)) if px else
+             (lambda: _ref_init_dense(env.observation_size, self.hidden_size, self.embedding_size))),
             ("actor", lambda: _ref_init_dense(feat, self.hidden_size, 2 * self.action_size)),
             ("critic", lambda: _ref_init_dense(feat, self.hidden_size, 1)),
         ):
@@ -83,14 +85,18 @@ class Dreamer:
             e.pack(g)
         self.transition_model = TransitionModel(self.belief_size, self.state_size, self.action_size, self.hidden_size,
                                                 self.embedding_size, engine=e)
-        self.observation_model = DenseModel(feat, self.hidden_size, env.observation_size, engine=e,
-                                            module="observation_model", prefix="obs")
+        if px:
+            self.observation_model = ObservationModel(self.belief_size, self.state_size, E, engine=e)
+            self.encoder = CnnImageEncoder(E, engine=e)
+        else:
+            self.observation_model = DenseModel(feat, self.hidden_size, env.observation_size, engine=e,
+                                                module="observation_model", prefix="obs")
+            self.encoder = encoder_for(e, env.observation_size, self.hidden_size, self.embedding_size)
         self.reward_model = DenseModel(feat, self.hidden_size, 1, engine=e, module="reward_model", prefix="rew")
-        self.encoder = encoder_for(e, env.observation_size, self.hidden_size, self.embedding_size)
         self.actor = ActorModel(self.belief_size, self.state_size, self.hidden_size, self.action_size, engine=e)
         self.critic = DenseModel(feat, self.hidden_size, 1, engine=e, module="critic", prefix="cri")
         self.critic_target = DenseModel(feat, self.hidden_size, 1, engine=e, module="critic_target", prefix="tgt")
-        self.buffer = ExperienceReplay(params["experience_size"], env.action_size, params["bit_depth"], False,
+        self.buffer = ExperienceReplay(params["experience_size"], env.action_size, params["bit_depth"], px,
                                        env.observation_size, self.device)
         self.load(params)
 
@@ -212,6 +218,24 @@ def _ref_init_dense(i: int, h: int, o: int) -> torch.nn.Module:
     layers += [nn.Linear(k, o), nn.Identity()]
     m = nn.Module()
     m.model = nn.Sequential(*layers)
+    return m
+
+
+def _ref_init_cnn(E: int) -> torch.nn.Module:
+    from torch import nn
+    m = nn.Module()
+    m.model = nn.Sequential(nn.Conv2d(3, 32, 4, 2), nn.ELU(), nn.Conv2d(32, 64, 4, 2), nn.ELU(), nn.Conv2d(64, 128, 4, 2),
+                            nn.ELU(), nn.Conv2d(128, 256, 4, 2), nn.ELU(), nn.Flatten(),
+                            nn.Identity() if E == 1024 else nn.Linear(1024, E))
+    return m
+
+
+def _ref_init_decoder(feat: int, E: int) -> torch.nn.Module:
+    from torch import nn
+    m = nn.Module()
+    m.decoder = nn.Sequential(nn.Linear(feat, E), nn.Identity(), nn.ConvTranspose2d(E, 128, 5, 2), nn.ELU(),
+                              nn.ConvTranspose2d(128, 64, 5, 2), nn.ELU(), nn.ConvTranspose2d(64, 32, 6, 2), nn.ELU(),
+                              nn.ConvTranspose2d(32, 3, 6, 2))
     return m
 
 

@@ -19,6 +19,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
+import torch.nn.functional as Fnn
 
 from . import _cabi as cabi
 from .parallel import DataParallel
@@ -106,6 +107,7 @@ class DreamerEngine:
     def __init__(self, dims: Dims, hp: Optional[dict] = None, device="cuda", params: Optional[dict] = None,
                  world_size: int = 1, process_group=None):
         self.d = dims
+        self.pixel = bool(dims.pixel)   # conv encoder / decoder through MIOpen (torch), everything else HIP kernels
         self.hp = dict(DEFAULT_HP)
         if hp:
             self.hp.update({k: v for k, v in hp.items() if k in self.hp})
@@ -225,8 +227,9 @@ class DreamerEngine:
         add("model", "q2m", Wq2[:S], tr=True)
         add("model", "q2s", Wq2[S:], tr=True)
         for l in range(DENSE_LAYERS + 1):
-            add("model", f"enc{l}", self.W("encoder", f"model.{2 * l}.weight"), tr=(l > 0))
-            add("model", f"obs{l}", self.W("observation_model", f"model.{2 * l}.weight"), tr=True)
+            if not self.pixel:
+                add("model", f"enc{l}", self.W("encoder", f"model.{2 * l}.weight"), tr=(l > 0))
+                add("model", f"obs{l}", self.W("observation_model", f"model.{2 * l}.weight"), tr=True)
             add("model", f"rew{l}", self.W("reward_model", f"model.{2 * l}.weight"), tr=True)
             add("critic", f"cri{l}", self.W("critic", f"model.{2 * l}.weight"), tr=(l > 0))
             add("critic_target", f"tgt{l}", self.W("critic_target", f"model.{2 * l}.weight"), tr=True)
@@ -336,6 +339,43 @@ class DreamerEngine:
         pre = self.buf("pre_emb", M, d.Hd)
         self.mlp_forward(M, obs2d, d.O, d.O, layers, acts + [emb, None], pre, d.Hd)
         return emb, pre
+
+    # ---- pixel observations: conv stacks on MIOpen through torch (the measured incumbent) ----
+    def _leaf_params(self, mod: str):
+        """Fresh autograd leaves aliasing the flat parameter buffer (name -> tensor), reference order."""
+        g = self.groups[self._mod_group[mod]]
+        return {n: g.p[(m, n)].detach().requires_grad_(True) for (m, n, _) in g.specs if m == mod}
+
+    def encode_pixels(self, obs4d: torch.Tensor, grad: bool = True):
+        """CnnImageEncoder (src/models.py:527-564) on (M,3,64,64) + the hoisted posterior projection (HIP)."""
+        d = self.d
+        M = obs4d.shape[0]
+        with torch.set_grad_enabled(grad):
+            w = self._leaf_params("encoder") if grad else self.state_dict("encoder")
+            x = obs4d
+            for i in range(4):
+                x = Fnn.elu(Fnn.conv2d(x, w[f"model.{2 * i}.weight"], w[f"model.{2 * i}.bias"], stride=2))
+            x = x.flatten(1)
+            if "model.9.weight" in w:
+                x = Fnn.linear(x, w["model.9.weight"], w["model.9.bias"])
+        self._enc_graph = (x, w) if grad else None
+        emb = x.detach().contiguous()
+        pre = self.buf("pre_emb", M, d.Hd)
+        self.mlp_forward(M, emb, d.E, d.E, [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)], None, pre, d.Hd)
+        return emb, pre
+
+    def decode_pixels(self, feat: torch.Tensor, grad: bool = True) -> torch.Tensor:
+        """ObservationModel (src/models.py:319-362): (M, Be+S) -> (M,3,64,64)."""
+        with torch.set_grad_enabled(grad):
+            w = self._leaf_params("observation_model") if grad else self.state_dict("observation_model")
+            f = feat.detach().requires_grad_(grad)
+            x = Fnn.linear(f, w["decoder.0.weight"], w["decoder.0.bias"]).view(feat.shape[0], -1, 1, 1)
+            for idx in (2, 4, 6, 8):
+                x = Fnn.conv_transpose2d(x, w[f"decoder.{idx}.weight"], w[f"decoder.{idx}.bias"], stride=2)
+                if idx != 8:
+                    x = Fnn.elu(x)
+        self._dec_graph = (x, w, f) if grad else None
+        return x
 
     def observe(self, actions, nonterm, pre_emb, eps_post, init_belief, init_state, T: int, B: int, save: bool = True,
                 tag: str = ""):
@@ -473,13 +513,16 @@ class DreamerEngine:
         # ======================= dynamics learning (dreamer.py:263-302) =======================
         obs_t = obs[1:].reshape(N, d.O)                     # targets and encoder input
         with self.span("encoder_fwd"):
-            emb, pre_emb = self.encode(obs_t, N)
+            emb, pre_emb = self.encode_pixels(obs[1:].reshape(N, 3, 64, 64)) if self.pixel else self.encode(obs_t, N)
         init_belief = self.buf("init_belief", B, d.Be).zero_()
         init_state = self.buf("init_state", B, d.S).zero_()
         feat, qm, qs = self.observe(actions[:-1], nonterm[:-1], pre_emb, noise["obs_post"], init_belief, init_state, T, B)
         with self.span("wm_heads_fwd"):
             _, pm, ps = self.prior_head(feat, N, noise["obs_prior"])
-            om_out, om_acts, om_layers = self.dense_forward("observation_model", "obs", "om", feat, F, N, d.O)
+            if self.pixel:
+                om_out, om_acts, om_layers = self.decode_pixels(feat).detach().view(N, d.O), None, None
+            else:
+                om_out, om_acts, om_layers = self.dense_forward("observation_model", "obs", "om", feat, F, N, d.O)
             rw_out, rw_acts, rw_layers = self.dense_forward("reward_model", "rew", "rw", feat, F, N, 1)
 
         inv_rows = self.dp.mean_grad_scale(N)
@@ -500,11 +543,22 @@ class DreamerEngine:
 
         # ---- backward of the world model ----
         dfeat = self.buf("dfeat", N, F)
-        om_dpre = [self.buf(f"om_dpre{l}", N, d.Hd) for l in range(DENSE_LAYERS)] + [d_om]
         rw_dpre = [self.buf(f"rw_dpre{l}", N, d.Hd) for l in range(DENSE_LAYERS)] + [d_rw]
-        self.mlp_backward(N, d_om, d.O, om_layers, om_acts + [None], om_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F)
-        self.mlp_backward(N, d_rw, 1, rw_layers, rw_acts + [None], rw_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F,
-                          accumulate=True)
+        if self.pixel:
+            self.mlp_backward(N, d_rw, 1, rw_layers, rw_acts + [None], rw_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F)
+            with self.span("decoder_bwd"):
+                pred, wdec, fleaf = self._dec_graph
+                names = list(wdec)
+                grads = torch.autograd.grad(pred, [wdec[n] for n in names] + [fleaf], d_om.view_as(pred))
+                for n, g in zip(names, grads[:-1]):
+                    self.G("observation_model", n).copy_(g)
+                dfeat.add_(grads[-1])
+                self._dec_graph = None
+        else:
+            om_dpre = [self.buf(f"om_dpre{l}", N, d.Hd) for l in range(DENSE_LAYERS)] + [d_om]
+            self.mlp_backward(N, d_om, d.O, om_layers, om_acts + [None], om_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F)
+            self.mlp_backward(N, d_rw, 1, rw_layers, rw_acts + [None], rw_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F,
+                              accumulate=True)
         # prior head: KL gradient on (mean, std) -> belief part of dfeat
         p_out, p_hid = self._buf["p_out"], self._buf["p_hid"]
         d_p_out, d_p_hid = self.buf("d_p_out", N, 2 * d.S), self.buf("d_p_hid", N, d.Hd)
@@ -536,10 +590,21 @@ class DreamerEngine:
             else:
                 cabi.check(lib.bd_observe_backward(C.byref(b), st))
         # encoder (+ hoisted projection as its last layer)
-        enc_layers = self._dense_spec("encoder", "enc", d.O, d.E) + [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)]
-        enc_acts = [self._buf[f"enc_act{l}"] for l in range(DENSE_LAYERS)]
-        enc_dpre = [self.buf(f"enc_dpre{l}", N, d.Hd) for l in range(DENSE_LAYERS)] + [self.buf("d_emb", N, d.E)]
-        self.mlp_backward(N, d_q1, d.Hd, enc_layers, enc_acts + [None, None], enc_dpre + [None])
+        if self.pixel:
+            d_emb = self.buf("d_emb", N, d.E)
+            self.mlp_backward(N, d_q1, d.Hd, [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)], [None], [None], din0=d_emb, ld0=d.E,
+                              w0=d.E)
+            with self.span("encoder_bwd"):
+                x, wenc = self._enc_graph
+                names = list(wenc)
+                for n, g in zip(names, torch.autograd.grad(x, [wenc[n] for n in names], d_emb)):
+                    self.G("encoder", n).copy_(g)
+                self._enc_graph = None
+        else:
+            enc_layers = self._dense_spec("encoder", "enc", d.O, d.E) + [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)]
+            enc_acts = [self._buf[f"enc_act{l}"] for l in range(DENSE_LAYERS)]
+            enc_dpre = [self.buf(f"enc_dpre{l}", N, d.Hd) for l in range(DENSE_LAYERS)] + [self.buf("d_emb", N, d.E)]
+            self.mlp_backward(N, d_q1, d.Hd, enc_layers, enc_acts + [None, None], enc_dpre + [None])
 
         # ---- weight gradients (into the flat model gradient buffer): one grouped launch ----
         Gt = lambda n: self.G("transition_model", n)
@@ -560,9 +625,10 @@ class DreamerEngine:
         wb.add(d_q2, 2 * d.S, self._buf["sv_q"], d.Hd, N, 2 * d.S, d.Hd, Gt("belief_posterior.model.2.weight"), d.Hd,
                Gt("belief_posterior.model.2.bias"))
         dense_sizes = lambda i, o: [i] + [d.Hd] * DENSE_LAYERS + [o]
-        self._dense_wgrads(wb, "observation_model", N, om_dpre, feat, F, om_acts, dense_sizes(F, d.O))
         self._dense_wgrads(wb, "reward_model", N, rw_dpre, feat, F, rw_acts, dense_sizes(F, 1))
-        self._dense_wgrads(wb, "encoder", N, enc_dpre, obs_t, d.O, enc_acts, dense_sizes(d.O, d.E))
+        if not self.pixel:      # (pixel mode: conv weight gradients came from MIOpen above)
+            self._dense_wgrads(wb, "observation_model", N, om_dpre, feat, F, om_acts, dense_sizes(F, d.O))
+            self._dense_wgrads(wb, "encoder", N, enc_dpre, obs_t, d.O, enc_acts, dense_sizes(d.O, d.E))
         with self.span("wgrad_model"):
             wb.run()
         with self.span("opt_model"):

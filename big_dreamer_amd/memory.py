@@ -2,7 +2,8 @@
 the storage mirrored in HBM and the batch gather done by a HIP kernel (bd_replay_gather), so that
 ``sample`` returns device tensors without a host-side gather or a bulk H2D copy.
 
-State observations only in this round (pixel replay: SURVEY.md section 8f, row 2)."""
+Pixel observations are kept as uint8 (5-bit quantised frames, as the reference stores them) and de-quantised on
+the device by bd_replay_gather_pixels; the dequantisation noise is drawn by torch's device generator."""
 from __future__ import annotations
 
 import numpy as np
@@ -13,13 +14,14 @@ from . import _cabi as cabi
 
 class ExperienceReplay:
     def __init__(self, size, action_size, bit_depth, pixel_observation, observation_size, device):
-        if pixel_observation:
-            raise NotImplementedError("pixel replay is not part of this round's hot path (DESIGN.md, scope)")
         self.device = torch.device(device)
         self.size = size
         self.pixel_observation = pixel_observation
         self.bit_depth = bit_depth
-        self.observations = np.empty((size, observation_size), dtype=np.float32)
+        if pixel_observation:
+            self.observations = np.empty((size, 3, 64, 64), dtype=np.uint8)
+        else:
+            self.observations = np.empty((size, observation_size), dtype=np.float32)
         self.actions = np.empty((size, action_size), dtype=np.float32)
         self.rewards = np.empty((size,), dtype=np.float32)
         self.nonterminals = np.empty((size, 1), dtype=np.float32)
@@ -34,7 +36,13 @@ class ExperienceReplay:
     # -- reference semantics (src/memory.py:33-49) --
     def append(self, observation, action, reward, done):
         to_np = lambda x: x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
-        self.observations[self.idx] = to_np(observation)
+        if self.pixel_observation:
+            # postprocess_observation (src/utils.py:320-337): [-0.5, 0.5] float -> quantised uint8
+            o = to_np(observation)
+            self.observations[self.idx] = np.clip(np.floor((o + 0.5) * 2 ** self.bit_depth) * 2 ** (8 - self.bit_depth),
+                                                  0, 2 ** 8 - 1).astype(np.uint8)
+        else:
+            self.observations[self.idx] = to_np(observation)
         self.actions[self.idx] = to_np(action)
         self.rewards[self.idx] = reward
         self.nonterminals[self.idx] = not done
@@ -94,8 +102,18 @@ class ExperienceReplay:
             self.sync_device()
         vidx = self._upload_indices(vec)
         out = []
+        if self.pixel_observation:
+            src = self._dev["observations"]
+            pixels = 3 * 64 * 64
+            noise = torch.rand(L * n * pixels, dtype=torch.float32, device=self.device)     # rand_like, src/utils.py:317
+            dst = torch.empty(L * n * pixels, dtype=torch.float32, device=self.device)
+            cabi.check(cabi.lib.bd_replay_gather_pixels(src.data_ptr(), vidx.data_ptr(), L * n, pixels, self.bit_depth,
+                                                        noise.data_ptr(), dst.data_ptr(), cabi.stream()))
+            out.append(dst.view(L, n, 3, 64, 64))
         for key, shape in (("observations", (L, n, -1)), ("actions", (L, n, -1)), ("rewards", (L, n)),
                            ("nonterminals", (L, n, 1))):
+            if key == "observations" and self.pixel_observation:
+                continue
             src = self._dev[key]
             width = src.numel() // src.shape[0]
             dst = torch.empty(L * n * width, dtype=torch.float32, device=self.device)

@@ -145,6 +145,46 @@ class ActorModel(_EngineBacked):
         self._bind(engine, "actor", "actor")
 
 
+class CnnImageEncoder(_EngineBacked):
+    """src/models.py:527-564: 4 x (Conv2d k4 s2 + ELU), Flatten, Identity | Linear(1024, E) -- ``model.{0,2,4,6[,9]}``.
+    The convolutions run on MIOpen through torch (measured incumbent)."""
+
+    def __init__(self, embedding_size: int, activation: str = "ELU", *, engine: DreamerEngine):
+        super().__init__()
+        assert activation == "ELU"
+        self.model = nn.Sequential(nn.Conv2d(3, 32, 4, 2), nn.ELU(), nn.Conv2d(32, 64, 4, 2), nn.ELU(),
+                                   nn.Conv2d(64, 128, 4, 2), nn.ELU(), nn.Conv2d(128, 256, 4, 2), nn.ELU(), nn.Flatten(),
+                                   nn.Identity() if embedding_size == 1024 else nn.Linear(1024, embedding_size))
+        self._bind(engine, "encoder", "model")
+
+    @torch.no_grad()
+    def forward(self, observation: Tensor) -> Tensor:
+        lead = observation.shape[:-3]
+        emb, _ = self._eng.encode_pixels(observation.reshape(-1, 3, 64, 64).contiguous().float(), grad=False)
+        return emb.view(*lead, -1).clone()
+
+
+class ObservationModel(_EngineBacked):
+    """src/models.py:319-362: Linear + 4 x ConvTranspose2d -- ``decoder.{0,2,4,6,8}``."""
+
+    def __init__(self, belief_size: int, state_size: int, embedding_size: int, activation: str = "ELU", *,
+                 engine: DreamerEngine):
+        super().__init__()
+        assert activation == "ELU"
+        self.output_shape = (3, 64, 64)
+        self.decoder = nn.Sequential(nn.Linear(belief_size + state_size, embedding_size), nn.Identity(),
+                                     nn.ConvTranspose2d(embedding_size, 128, 5, 2), nn.ELU(),
+                                     nn.ConvTranspose2d(128, 64, 5, 2), nn.ELU(), nn.ConvTranspose2d(64, 32, 6, 2), nn.ELU(),
+                                     nn.ConvTranspose2d(32, 3, 6, 2))
+        self._bind(engine, "observation_model", "model")
+
+    @torch.no_grad()
+    def forward(self, belief: Tensor, state: Tensor) -> Tensor:
+        lead = belief.shape[:-1]
+        x = torch.cat([belief, state], dim=-1).reshape(-1, belief.shape[-1] + state.shape[-1]).contiguous().float()
+        return self._eng.decode_pixels(x, grad=False).view(*lead, 3, 64, 64).clone()
+
+
 def encoder_for(engine: DreamerEngine, observation_size: int, hidden_size: int, embedding_size: int) -> DenseModel:
     """State-observation encoder (src/planet.py:195-200)."""
     return DenseModel(observation_size, hidden_size, embedding_size, engine=engine, module="encoder", prefix="enc")

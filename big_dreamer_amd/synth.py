@@ -31,6 +31,7 @@ class Dims:
     A: int = 1       # action_size (Pendulum 1)
     O: int = 3       # observation_size (Pendulum 3, state observations)
     n_entropy: int = 100  # SampleDist samples (src/models.py:681)
+    pixel: bool = False   # 64x64x3 pixel observations (conv encoder / decoder, src/models.py:319-362,527-564)
 
     @property
     def T(self) -> int:
@@ -52,7 +53,11 @@ class Dims:
 
 CONFIG1 = Dims(B=50, L=50, H=15, Be=32, S=30, Hd=32, E=1024, A=1, O=3)     # BASELINE.json configs[0]
 CONFIG2 = Dims()                                                           # BASELINE.json configs[1]
+PIXEL_SHAPE = (3, 64, 64)
 TINY = Dims(B=3, L=5, H=4, Be=24, S=6, Hd=20, E=40, A=2, O=5, n_entropy=100)
+TINY_PIXEL = Dims(B=2, L=4, H=3, Be=24, S=6, Hd=20, E=1024, A=2, O=12288, pixel=True)      # Identity after Flatten
+TINY_PIXEL_LIN = Dims(B=2, L=3, H=3, Be=20, S=5, Hd=24, E=48, A=1, O=12288, pixel=True)     # Linear(1024, E) tail
+CONFIG3 = Dims(A=17, O=12288, pixel=True)                                                   # BASELINE.json configs[2]
 SMALL = Dims(B=7, L=9, H=6, Be=48, S=10, Hd=36, E=72, A=3, O=4, n_entropy=100)
 
 DENSE_LAYERS = 4  # DenseModel / ActorModel n_layers (src/models.py:378,482)
@@ -91,11 +96,24 @@ def param_shapes(d: Dims) -> Dict[str, List[Tuple[str, Tuple[int, ...]]]]:
     def strip(lst):
         return [(n.split(".", 1)[1], s) for n, s in lst]
 
+    if d.pixel:
+        # CnnImageEncoder.model (src/models.py:538-552) / ObservationModel.decoder (src/models.py:338-348)
+        enc = []
+        for i, (ci, co) in enumerate([(3, 32), (32, 64), (64, 128), (128, 256)]):
+            enc += [(f"model.{2 * i}.weight", (co, ci, 4, 4)), (f"model.{2 * i}.bias", (co,))]
+        if d.E != 1024:
+            enc += [("model.9.weight", (d.E, 1024)), ("model.9.bias", (d.E,))]
+        obs = [("decoder.0.weight", (d.E, feat)), ("decoder.0.bias", (d.E,))]
+        for idx, (ci, co, k) in zip((2, 4, 6, 8), [(d.E, 128, 5), (128, 64, 5), (64, 32, 6), (32, 3, 6)]):
+            obs += [(f"decoder.{idx}.weight", (ci, co, k, k)), (f"decoder.{idx}.bias", (co,))]
+    else:
+        enc = strip(_mlp_shapes("x", [d.O] + hid + [d.E]))
+        obs = strip(_mlp_shapes("x", [feat] + hid + [d.O]))
     return {
         "transition_model": tm,
-        "observation_model": strip(_mlp_shapes("x", [feat] + hid + [d.O])),
+        "observation_model": obs,
         "reward_model": strip(_mlp_shapes("x", [feat] + hid + [1])),
-        "encoder": strip(_mlp_shapes("x", [d.O] + hid + [d.E])),
+        "encoder": enc,
         "actor": strip(_mlp_shapes("x", [feat] + hid + [2 * d.A])),
         "critic": strip(_mlp_shapes("x", [feat] + hid + [1])),
     }
@@ -116,6 +134,9 @@ def make_params(d: Dims, seed: int = 0) -> Dict[str, Dict[str, np.ndarray]]:
         for name, shape in lst:
             if name.startswith("rnn."):
                 bound = 1.0 / np.sqrt(d.Be)
+            elif len(shape) == 4:      # conv / conv-transpose kernels: fan_in = dim1 * kh * kw (PyTorch convention)
+                fan_in = shape[1] * shape[2] * shape[3]
+                bound = 1.0 / np.sqrt(fan_in)
             elif len(shape) == 2:
                 fan_in = shape[1]
                 bound = 1.0 / np.sqrt(fan_in)
@@ -145,8 +166,13 @@ def make_batch(d: Dims, seed: int = 0, p_terminal: float = 0.02) -> Dict[str, np
     Terminals are made more frequent than in the replay so that small batches exercise the
     nonterminal mask (src/models.py:247)."""
     rng = np.random.Generator(np.random.PCG64(seed + 1000))
+    if d.pixel:   # as ExperienceReplay.sample returns pixels: 5-bit quantised, centred, dequantised (src/utils.py:299-317)
+        q = rng.integers(0, 32, size=(d.L, d.B) + PIXEL_SHAPE).astype(np.float32)
+        obs = q / 32.0 - 0.5 + rng.random((d.L, d.B) + PIXEL_SHAPE, dtype=np.float32) / 32.0
+    else:
+        obs = rng.standard_normal((d.L, d.B, d.O), dtype=np.float32)
     return {
-        "observations": rng.standard_normal((d.L, d.B, d.O), dtype=np.float32),
+        "observations": obs,
         "actions": rng.uniform(-1.0, 1.0, size=(d.L, d.B, d.A)).astype(np.float32),
         "rewards": rng.standard_normal((d.L, d.B), dtype=np.float32),
         "nonterminals": (rng.random((d.L, d.B, 1)) >= p_terminal).astype(np.float32),

@@ -303,6 +303,12 @@ int bd_polyak(float* target, const float* src, size_t n, float weight, void* str
 /* ---- replay gather: ExperienceReplay._retrieve_batch (src/memory.py:70-85) --------------------- */
 int bd_replay_gather(const float* src, const int64_t* idx, int n_idx, int width, float* dst, void* stream);
 
+/* pixel replay: gather uint8 frames (pixels bytes per row, multiple of 4) and dequantise in one pass:
+ * out = floor(u8 / 2^(8-bits)) / 2^bits - 0.5 + noise / 2^bits  (preprocess_observation_, src/utils.py:299-317;
+ * noise ~ U[0,1) is an explicit [n_idx x pixels] input) */
+int bd_replay_gather_pixels(const unsigned char* src, const int64_t* idx, int n_idx, int pixels, int bit_depth,
+                            const float* noise, float* dst, void* stream);
+
 size_t bd_reduce_ws_floats(void);
 
 #ifdef __cplusplus

@@ -37,6 +37,30 @@ def mlp(x: Tensor, sd: Dict[str, Tensor], n_hidden: int = 4) -> Tensor:
     return F.linear(x, sd[f"model.{2 * n_hidden}.weight"], sd[f"model.{2 * n_hidden}.bias"])
 
 
+def cnn_encoder(obs: Tensor, sd: Dict[str, Tensor]) -> Tensor:
+    """CnnImageEncoder.forward (src/models.py:527-564): 4 x (Conv2d k4 s2 + ELU), Flatten, Identity | Linear(1024, E)."""
+    lead = obs.shape[:-3]
+    x = obs.reshape(-1, *obs.shape[-3:])
+    for i in range(4):
+        x = F.elu(F.conv2d(x, sd[f"model.{2 * i}.weight"], sd[f"model.{2 * i}.bias"], stride=2))
+    x = x.flatten(1)
+    if "model.9.weight" in sd:
+        x = F.linear(x, sd["model.9.weight"], sd["model.9.bias"])
+    return x.reshape(*lead, -1)
+
+
+def cnn_decoder(belief: Tensor, state: Tensor, sd: Dict[str, Tensor]) -> Tensor:
+    """ObservationModel.forward (src/models.py:350-362): Linear, reshape (E,1,1), 4 x ConvTranspose2d (ELU between)."""
+    lead = belief.shape[:-1]
+    x = F.linear(torch.cat([belief, state], dim=-1), sd["decoder.0.weight"], sd["decoder.0.bias"])
+    x = x.reshape(-1, x.shape[-1], 1, 1)
+    for idx in (2, 4, 6, 8):
+        x = F.conv_transpose2d(x, sd[f"decoder.{idx}.weight"], sd[f"decoder.{idx}.bias"], stride=2)
+        if idx != 8:
+            x = F.elu(x)
+    return x.reshape(*lead, 3, 64, 64)
+
+
 def dense_on_features(belief: Tensor, state: Tensor, sd: Dict[str, Tensor]) -> Tensor:
     """DenseModel.forward(belief, state) = model(cat(belief, state, -1)) (src/models.py:393-408)."""
     return mlp(torch.cat([belief, state], dim=-1), sd)
@@ -285,11 +309,15 @@ class OracleDreamer:
         S = P["transition_model"]["belief_prior.model.2.weight"].size(0) // 2
         init_belief = torch.zeros(B, Be)
         init_state = torch.zeros(B, S)
-        emb = mlp(obs[1:], P["encoder"])                                                       # :270
+        pixel = obs.dim() == 5
+        emb = cnn_encoder(obs[1:], P["encoder"]) if pixel else mlp(obs[1:], P["encoder"])      # :270
         beliefs, prior_states, prior_params, post_states, post_params = transition_forward(
             P["transition_model"], init_state, actions[:-1], init_belief, emb, nonterm[:-1],
             noise["obs_prior"], noise["obs_post"])                                             # :272-278
-        obs_loss = normal_nll_mean(dense_on_features(beliefs, post_states, P["observation_model"]), obs[1:])
+        if pixel:   # Independent(Normal(means, 1), 3) (src/planet.py:264-265)
+            obs_loss = normal_nll_mean(cnn_decoder(beliefs, post_states, P["observation_model"]), obs[1:], event_dims=3)
+        else:
+            obs_loss = normal_nll_mean(dense_on_features(beliefs, post_states, P["observation_model"]), obs[1:])
         rew_pred = dense_on_features(beliefs, post_states, P["reward_model"])
         rew_loss = normal_nll_mean(rew_pred, rewards[:-1].unsqueeze(-1))
         kl = kl_loss(post_params, prior_params, hp["kl_balance"], hp["free_nats"])

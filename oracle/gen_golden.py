@@ -52,7 +52,7 @@ def _import_reference():
 class FakeEnv:
     def __init__(self, d):
         self.action_size = d.A
-        self.observation_size = d.O
+        self.observation_size = (3, 64, 64) if d.pixel else d.O
 
 
 def ref_params(d: synth.Dims, **over):
@@ -70,9 +70,9 @@ def ref_params(d: synth.Dims, **over):
         return x
 
     p = coerce(p)
-    p.update(dict(disable_cuda=True, pixel_observation=False, belief_size=d.Be, state_size=d.S,
+    p.update(dict(disable_cuda=True, pixel_observation=bool(d.pixel), belief_size=d.Be, state_size=d.S,
                   hidden_size=d.Hd, embedding_size=d.E, batch_size=d.B, seq_len=d.L,
-                  planning_horizon=d.H, experience_size=6000))
+                  planning_horizon=d.H, experience_size=6000 if not d.pixel else 64))
     p.update(over)
     return p
 
@@ -227,6 +227,27 @@ def run_replay(memory_mod):
     print(f"wrote {path}")
 
 
+def run_pixel_preprocess():
+    """R0 (pixels): preprocess_observation_ (src/utils.py:299-317) on uint8 frames with injected uniform noise."""
+    import utils as ref_utils
+    rng = np.random.Generator(np.random.PCG64(77))
+    u8 = rng.integers(0, 256, size=(6, 3, 64, 64), dtype=np.uint8)
+    noise = rng.random((6, 3, 64, 64), dtype=np.float32)
+    out = {"u8": u8, "noise": noise}
+    for bits in (5, 8, 3):
+        x = torch.as_tensor(u8.astype(np.float32))
+        orig = torch.rand_like
+        torch.rand_like = lambda t, **kw: torch.from_numpy(noise.copy())
+        try:
+            ref_utils.preprocess_observation_(x, bits)
+        finally:
+            torch.rand_like = orig
+        out[f"out{bits}"] = x.numpy().copy()
+    path = os.path.join(ROOT, "tests", "golden", "pixel_preprocess.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -237,6 +258,9 @@ def main():
     # the sum-KL branch end to end (kl_balance = -1) and an unsaturated free-nats setting
     run_config(dreamer_mod, "tiny_klsum", synth.TINY, full=True, seed=2, kl_balance=-1, free_nats=0.05)
     run_config(dreamer_mod, "tiny_freenats0", synth.TINY, full=True, seed=3, free_nats=0.0)
+    run_config(dreamer_mod, "tiny_pixel", synth.TINY_PIXEL, full=False, seed=4)
+    run_config(dreamer_mod, "tiny_pixel_lin", synth.TINY_PIXEL_LIN, full=False, seed=5)
+    run_pixel_preprocess()
     run_config(dreamer_mod, "config1", synth.CONFIG1, full=False)
     run_config(dreamer_mod, "config2", synth.CONFIG2, full=False)
 

@@ -13,6 +13,8 @@ CASES = {
     "small": (synth.SMALL, 1, {}, True),
     "tiny_klsum": (synth.TINY, 2, dict(kl_balance=-1, free_nats=0.05), True),
     "tiny_freenats0": (synth.TINY, 3, dict(free_nats=0.0), True),
+    "tiny_pixel": (synth.TINY_PIXEL, 4, {}, False),
+    "tiny_pixel_lin": (synth.TINY_PIXEL_LIN, 5, {}, False),
     "config1": (synth.CONFIG1, 0, {}, False),
     "config2": (synth.CONFIG2, 0, {}, False),
 }

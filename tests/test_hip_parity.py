@@ -95,7 +95,8 @@ def test_forward_pieces_vs_oracle(name):
 
 @pytest.mark.parametrize("name,cluster", [("tiny", True), ("small", True), ("tiny_klsum", True), ("tiny_freenats0", True),
                                           ("config1", True), ("config2", True), ("small", False),
-                                          ("tiny_freenats0", False), ("config2", False)])
+                                          ("tiny_freenats0", False), ("config2", False),
+                                          ("tiny_pixel", True), ("tiny_pixel_lin", True)])
 def test_train_steps_vs_oracle_and_golden(name, cluster):
     """Two whole train steps: losses, clipped gradients, gradient norms, post-Adam weights -- with the observe
     scan run by the multi-CU cluster kernels (default) and by the single-workgroup kernels."""
@@ -163,3 +164,26 @@ def test_replay_sample_on_device_matches_reference_golden():
         np.testing.assert_array_equal(a.cpu().numpy(), g[f"{case}.actions"])
         np.testing.assert_array_equal(r.cpu().numpy(), g[f"{case}.rewards"])
         np.testing.assert_array_equal(n.cpu().numpy(), g[f"{case}.nonterminals"])
+
+
+def test_pixel_replay_gather_dequantise_matches_reference():
+    """R0 (pixels): bd_replay_gather_pixels == preprocess_observation_ of the reference (golden, injected noise)."""
+    from big_dreamer_amd import _cabi as cabi
+    g = load_golden("pixel_preprocess")
+    u8 = torch.as_tensor(g["u8"]).cuda().contiguous()
+    noise = torch.as_tensor(g["noise"]).cuda().contiguous()
+    idx = torch.arange(u8.shape[0], dtype=torch.int64, device="cuda")
+    for bits in (5, 8, 3):
+        out = torch.empty(u8.shape, dtype=torch.float32, device="cuda")
+        cabi.check(cabi.lib.bd_replay_gather_pixels(u8.data_ptr(), idx.data_ptr(), u8.shape[0], 3 * 64 * 64, bits,
+                                                    noise.data_ptr(), out.data_ptr(), cabi.stream()))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), g[f"out{bits}"])     # bit exact
+    # permuted gather
+    perm = torch.tensor([3, 0, 5, 5, 1], dtype=torch.int64, device="cuda")
+    out = torch.empty(5, 3, 64, 64, dtype=torch.float32, device="cuda")
+    cabi.check(cabi.lib.bd_replay_gather_pixels(u8.data_ptr(), perm.data_ptr(), 5, 3 * 64 * 64, 5, noise.data_ptr(),
+                                                out.data_ptr(), cabi.stream()))
+    torch.cuda.synchronize()
+    want = np.floor(g["u8"][[3, 0, 5, 5, 1]].astype(np.float32) / 8) / 32 - 0.5 + g["noise"][:5] / 32
+    np.testing.assert_array_equal(out.cpu().numpy(), want.astype(np.float32))
