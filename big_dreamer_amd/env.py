@@ -48,8 +48,36 @@ class SyntheticEnv:
         pass
 
 
+class SyntheticPixelEnv(SyntheticEnv):
+    """Same dynamics, observed as a 3x64x64 image in [-0.5, 0.5]: a fixed random linear rendering of the state
+    squashed with tanh (stands in for the reference's rendered gym frames, src/env.py:235-317)."""
+
+    def __init__(self, state_size: int = 3, action_size: int = 1, max_episode_length: int = 1000, action_repeat: int = 2,
+                 seed: int = 0):
+        super().__init__(state_size, action_size, max_episode_length, action_repeat, seed)
+        self._render = (self.rng.standard_normal((3 * 64 * 64, state_size)) / np.sqrt(state_size)).astype(np.float32)
+        self.state_size = state_size
+        self.observation_size = (3, 64, 64)
+
+    def _img(self):
+        return torch.from_numpy((0.5 * np.tanh(self._render @ self.x)).astype(np.float32).reshape(1, 3, 64, 64))
+
+    def reset(self):
+        self.t = 0
+        self.x = self.rng.standard_normal(self.state_size).astype(np.float32)
+        return self._img()
+
+    def step(self, action):
+        _, reward, done = super().step(action)
+        return self._img(), reward, done
+
+
 def Env(params):
     """Factory with the reference's name (src/env.py:320-340)."""
+    if params.get("pixel_observation", False):
+        return SyntheticPixelEnv(int(params.get("synthetic_env_observation_size", 3)),
+                                 int(params.get("synthetic_env_action_size", 1)), int(params["max_episode_length"]),
+                                 int(params["action_repeat"]), int(params["seed"]))
     return SyntheticEnv(int(params.get("synthetic_env_observation_size", 3)),
                         int(params.get("synthetic_env_action_size", 1)), int(params["max_episode_length"]),
                         int(params["action_repeat"]), int(params["seed"]))

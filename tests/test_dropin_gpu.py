@@ -118,3 +118,33 @@ def test_cli_runs_like_the_reference():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "Initialized with" in out.stdout and "model_loss" in out.stdout
+
+
+def test_pixel_agent_surface():
+    """pixel_observation=True: uint8 replay + HIP dequantise, conv encoder/decoder modules with the reference's
+    state_dict names, train_step and update_belief_and_act."""
+    from big_dreamer_amd.config import load_config
+    from big_dreamer_amd.dreamer import Dreamer
+    from big_dreamer_amd.env import SyntheticPixelEnv
+    d = synth.TINY_PIXEL
+    params = load_config([f"belief_size={d.Be}", f"state_size={d.S}", f"hidden_size={d.Hd}", "embedding_size=1024",
+                          "batch_size=2", "seq_len=4", "planning_horizon=3", "experience_size=200", "seed_steps=60",
+                          "max_episode_length=20", "pixel_observation=true"])
+    env = SyntheticPixelEnv(3, d.A, 20, 2, 0)
+    agent = Dreamer(params, env)
+    P = synth.make_params(d, 4)
+    for mod in ("transition_model", "observation_model", "reward_model", "encoder", "actor", "critic"):
+        m = getattr(agent, mod)
+        assert list(m.state_dict().keys()) == [n for n, _ in synth.param_shapes(d)[mod]]
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in P[mod].items()})
+    np.random.seed(0)
+    agent.randomly_initialize_replay_buffer()
+    assert agent.buffer.observations.dtype == np.uint8
+    logs = agent.train_step()
+    assert all(np.isfinite(v) for v in logs.values()) and logs["observation_loss"] > 1000.0   # 12288 dims * ~0.92
+    obs = env.reset()
+    out = agent.update_belief_and_act(env, torch.zeros(1, d.Be).cuda(), torch.zeros(1, d.S).cuda(),
+                                      torch.zeros(1, d.A).cuda(), obs, explore=True)
+    assert out[0].shape == (1, d.Be) and out[2].shape == (1, d.A)
+    img = agent.observation_model(out[0], out[1])
+    assert tuple(img.shape) == (1, 3, 64, 64)
