@@ -14,6 +14,7 @@ class SyntheticEnv:
     def __init__(self, observation_size: int = 3, action_size: int = 1, max_episode_length: int = 1000,
                  action_repeat: int = 2, seed: int = 0):
         self.observation_size, self.action_size = observation_size, action_size
+        self._nx = observation_size          # state dimension (the pixel subclass changes observation_size)
         self.max_episode_length, self.action_repeat = max_episode_length, action_repeat
         rng = np.random.default_rng(seed)
         q, _ = np.linalg.qr(rng.standard_normal((observation_size, observation_size)))
@@ -25,7 +26,7 @@ class SyntheticEnv:
 
     def reset(self) -> torch.Tensor:
         self.t = 0
-        self.x = self.rng.standard_normal(self.observation_size).astype(np.float32)
+        self.x = self.rng.standard_normal(self._nx).astype(np.float32)
         return torch.from_numpy(self.x.copy()).unsqueeze(0)
 
     def step(self, action):
@@ -33,7 +34,7 @@ class SyntheticEnv:
                        dtype=np.float32).reshape(-1)[: self.action_size]
         reward = 0.0
         for _ in range(self.action_repeat):
-            self.x = self.A @ self.x + self.B @ u + 0.01 * self.rng.standard_normal(self.observation_size).astype(np.float32)
+            self.x = self.A @ self.x + self.B @ u + 0.01 * self.rng.standard_normal(self._nx).astype(np.float32)
             reward += float(-(self.x ** 2).sum() - 0.1 * (u ** 2).sum())
             self.t += 1
             if self.t >= self.max_episode_length:
