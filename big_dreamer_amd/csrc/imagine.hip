@@ -39,27 +39,34 @@ struct ImgDims {
 
 // One sample of the entropy estimate: log-density of y = tanh(mean + std*e) under the tanh-Normal, and its
 // derivatives w.r.t. mean and std following the reference's autograd graph (rsample -> tanh -> clamp ->
-// atanh -> Normal.log_prob - log|det J|).
-__device__ __forceinline__ void entropy_sample(float mean, float sd, float e, float& lp, float& dm, float& ds) {
+// atanh -> Normal.log_prob - log|det J|).  Terms that depend only on (row, action dim) -- log std, 1/std^2,
+// 1/std -- are hoisted by the caller; exp(-2x) is shared by softplus(-2x) and sigmoid(-2x).
+struct EntConst {
+    float mean, sd, inv_var, inv_sd, base0;     // base0 = -log(sd) - log(sqrt(2 pi)) - 2 ln 2
+};
+__device__ __forceinline__ EntConst entropy_const(float mean, float sd) {
+    constexpr float kLogSqrt2Pi = 0.91893853320467274f, kLn2 = 0.69314718055994531f;
+    return EntConst{mean, sd, 1.f / (sd * sd), 1.f / sd, -logf(sd) - kLogSqrt2Pi - 2.f * kLn2};
+}
+__device__ __forceinline__ void entropy_sample(const EntConst& c, float e, float& lp, float& dm, float& ds) {
     constexpr float kClamp = 0.99999994f;                // float32(0.99999997), src/models.py:663
-    constexpr float kLogSqrt2Pi = 0.91893853320467274f;
-    constexpr float kLn2 = 0.69314718055994531f;
-    const float u = mean + sd * e;
+    const float u = c.mean + c.sd * e;
     const float y = tanhf(u);
     const float yc = fminf(fmaxf(y, -kClamp), kClamp);
     const float a = 1.f + yc, b = 1.f - yc;
-    const float w = a / b;
-    const float xh = 0.5f * logf(w);                     // atanh (src/models.py:627)
-    const float diff = xh - mean;
-    const float inv_var = 1.f / (sd * sd);
-    const float base = -(diff * diff) * 0.5f * inv_var - logf(sd) - kLogSqrt2Pi;
-    const float ladj = 2.f * (kLn2 - xh - softplusf(-2.f * xh));   // src/models.py:673
-    lp = base - ladj;
-    const float gx = -diff * inv_var + 2.f - 4.f * sigmoidf(-2.f * xh);     // d lp / d xh
+    const float xh = 0.5f * logf(a / b);                 // atanh (src/models.py:627)
+    const float diff = xh - c.mean;
+    const float t = -2.f * xh;
+    const float ex = expf(t);                            // shared: softplus(t) = log1p(ex), sigmoid(t) = ex / (1 + ex)
+    const float sp = t > 20.f ? t : log1pf(ex);          // F.softplus threshold
+    const float sg = t > 20.f ? 1.f : ex / (1.f + ex);
+    // log p = -(xh-mean)^2/(2 sd^2) - log sd - log sqrt(2pi) - 2 (ln 2 - xh - softplus(-2 xh))     (src/models.py:673)
+    lp = c.base0 - 0.5f * diff * diff * c.inv_var + 2.f * (xh + sp);
+    const float gx = -diff * c.inv_var + 2.f - 4.f * sg;                    // d lp / d xh
     const bool pass = (y >= -kClamp) && (y <= kClamp);                      // clamp backward mask
-    const float J = pass ? (1.f - y * y) * (0.5f / w) * (1.f / b + a / (b * b)) : 0.f;   // d xh / d u
-    dm = diff * inv_var + gx * J;
-    ds = diff * diff * inv_var / sd - 1.f / sd + gx * J * e;
+    const float J = pass ? (1.f - y * y) / (a * b) : 0.f;                   // d xh / d u = (1 - y^2) / ((1+yc)(1-yc))
+    dm = diff * c.inv_var + gx * J;
+    ds = diff * diff * c.inv_var * c.inv_sd - c.inv_sd + gx * J * e;
 }
 
 // hidden layer epilogue: ELU -> LDS fragment (+ optional save for the backward)
@@ -231,11 +238,11 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
             for (int j = 0; j < A; ++j) {
                 float lp = 0.f, dm = 0.f, ds = 0.f;
                 if (grow < a.N) {
-                    const float mean = mean_s[row * A + j], sd = std_s[row * A + j];
+                    const EntConst ec = entropy_const(mean_s[row * A + j], std_s[row * A + j]);
                     for (int k = sl; k < a.n_samples; k += kThreads / 16) {
                         const float e = a.eps_entropy[(((size_t)t * a.n_samples + k) * a.N + grow) * A + j];
                         float l1, d1, d2;
-                        entropy_sample(mean, sd, e, l1, d1, d2);
+                        entropy_sample(ec, e, l1, d1, d2);
                         lp += l1; dm += d1; ds += d2;
                     }
                 }
