@@ -192,6 +192,18 @@ class Dreamer:
         return belief, posterior_state, action, next_observation, reward, done
 
 
+class DreamerV2(Dreamer):
+    """src/dreamerV2.py:13-25: Dreamer with the V2 KL settings (balanced KL; kl_loss_weight 1.0 is replaced by
+    0.1).  Gaussian latents only -- the reference's Categorical path crashes at HEAD."""
+
+    def __init__(self, params: Dict[str, Any], env, **kw):
+        p = dict(params)
+        if p.get("kl_loss_weight") == 1.0:
+            p["kl_loss_weight"] = 0.1
+        super().__init__(p, env, **kw)
+        self.kl_balance = p["kl_balance"]
+
+
 def lambda_return(imged_reward: Tensor, value_pred: Tensor, bootstrap: Tensor, discount: float = 0.99,
                   lambda_: float = 0.95) -> Tensor:
     """src/dreamer.py:447-471 on the GPU (bd_lambda_return_forward).  The kernel takes the bootstrap from the

@@ -389,8 +389,10 @@ class DreamerEngine:
         return x
 
     def observe(self, actions, nonterm, pre_emb, eps_post, init_belief, init_state, T: int, B: int, save: bool = True,
-                tag: str = ""):
-        """TransitionModel.forward recurrence (posterior path).  Returns feat [T*B x (Be+S)], post_mean, post_std."""
+                tag: str = "", prior_only: bool = False):
+        """TransitionModel.forward recurrence.  Returns feat [T*B x (Be+S)], mean, std of the fed-back state:
+        the posterior (embeddings given) or, with prior_only=True (embeddings=None, src/models.py:241,296-297), the
+        prior -- the same kernel run with the prior head's weights and a zero embedding projection."""
         d, pk = self.d, self.pk
         tm = lambda n: self.W("transition_model", n)
         M = T * B
@@ -400,8 +402,13 @@ class DreamerEngine:
         a.w_ir, a.w_iz, a.w_in = ptr(pk["ir"]), ptr(pk["iz"]), ptr(pk["in"])
         a.w_hr, a.w_hz, a.w_hn = ptr(pk["hr"]), ptr(pk["hz"]), ptr(pk["hn"])
         a.b_ih, a.b_hh = ptr(tm("rnn.bias_ih")), ptr(tm("rnn.bias_hh"))
-        a.w_q1h, a.b_q1 = ptr(pk["q1h"]), ptr(tm("belief_posterior.model.0.bias"))
-        a.w_q2m, a.w_q2s, a.b_q2 = ptr(pk["q2m"]), ptr(pk["q2s"]), ptr(tm("belief_posterior.model.2.bias"))
+        if prior_only:
+            a.w_q1h, a.b_q1 = ptr(pk["p1"]), ptr(tm("belief_prior.model.0.bias"))
+            a.w_q2m, a.w_q2s, a.b_q2 = ptr(pk["p2m"]), ptr(pk["p2s"]), ptr(tm("belief_prior.model.2.bias"))
+            pre_emb = self.buf(tag + "zero_pre_emb", M, d.Hd)       # stays zero: nothing ever writes it
+        else:
+            a.w_q1h, a.b_q1 = ptr(pk["q1h"]), ptr(tm("belief_posterior.model.0.bias"))
+            a.w_q2m, a.w_q2s, a.b_q2 = ptr(pk["q2m"]), ptr(pk["q2s"]), ptr(tm("belief_posterior.model.2.bias"))
         a.init_belief, a.init_state, a.actions = ptr(init_belief), ptr(init_state), ptr(actions)
         a.nonterm, a.pre_emb, a.eps_post = ptr(nonterm), ptr(pre_emb), ptr(eps_post)
         a.min_std = self.hp["min_std_dev"]

@@ -102,14 +102,20 @@ class TransitionModel(_EngineBacked):
                 nonterminals: Optional[Tensor] = None, _noise: Optional[Tuple[Tensor, Tensor]] = None):
         """init_state (B,S), actions (T,B,A), init_belief (B,Be), embeddings (T,B,E), nonterminals (T,B,1) ->
         beliefs (T,B,Be), prior_states, (prior_means, prior_stds), posterior_states, (post_means, post_stds)."""
-        if embeddings is None:
-            raise NotImplementedError("prior-only rollout (embeddings=None) is only used by the PlaNet MPC planner, "
-                                      "which is outside this build's hot path (DESIGN.md, scope)")
         eng = self._eng
         Be, S, A, Hd, E = self._dims
         T, B = actions.shape[0], actions.shape[1]
         M = T * B
         f = lambda t: t.contiguous().float()
+        if embeddings is None:
+            # prior-only rollout (src/models.py:241,296-297; the MPC planner's call, src/planner.py:65): the sampled
+            # prior state is fed back; posterior outputs are None
+            eps_p = torch.randn(T, B, S, device=eng.dev) if _noise is None else f(_noise[0])
+            feat, pm, ps = eng.observe(f(actions), None if nonterminals is None else f(nonterminals), None, eps_p,
+                                       f(init_belief), f(init_state), T, B, save=False, tag="api_", prior_only=True)
+            feat = feat.view(T, B, Be + S)
+            v = lambda t: t.clone().view(T, B, S)
+            return feat[..., :Be].clone(), feat[..., Be:].clone(), (v(pm), v(ps)), None, None
         pre = eng.buf("api_pre_emb", M, Hd)
         eng.mlp_forward(M, f(embeddings).view(M, E), E, E, [("q1e", None, Hd, E, 0)], None, pre, Hd)
         if _noise is None:      # (prior eps, posterior eps); the parity tests inject the oracle's draws

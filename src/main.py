@@ -25,15 +25,15 @@ def my_app(argv):
     np.random.seed(params["seed"] + rank)
     torch.manual_seed(params["seed"])                 # identical initial weights on every rank
     random.seed(params["seed"] + rank)
-    if params["algorithm"] not in ("dreamer",):
+    if params["algorithm"] not in ("dreamer", "dreamerV2"):      # planet (MPC) is outside this build's hot path
         raise NotImplementedError(f'algorithm {params["algorithm"]} is not yet implemented.')
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
     if world > 1:
         torch.distributed.init_process_group("nccl")
-    from big_dreamer_amd.dreamer import Dreamer
+    from big_dreamer_amd.dreamer import Dreamer, DreamerV2
     from big_dreamer_amd.env import Env
     env = Env(params)
-    model = Dreamer(params, env, world_size=world)
+    model = (DreamerV2 if params["algorithm"] == "dreamerV2" else Dreamer)(params, env, world_size=world)
     torch.manual_seed(params["seed"] + rank)
     env_steps, num_episodes = model.randomly_initialize_replay_buffer()
     if rank == 0:

@@ -54,6 +54,15 @@ def test_state_dict_roundtrip_and_module_forward_match_oracle():
                           flat(out), flat(want)):
         assert tuple(g.shape) == tuple(w.shape)
         assert_close(name, g.cpu().numpy(), w.numpy(), 2e-5, 2e-5)
+    # prior-only mode (embeddings=None): what the MPC planner calls (src/planner.py:65)
+    pout = agent.transition_model(torch.zeros(d.B, d.S).cuda(), cu(batch["actions"][:-1]), torch.zeros(d.B, d.Be).cuda(),
+                                  None, None, _noise=(cu(noise["obs_prior"]), None))
+    pwant = O.transition_forward(tP["transition_model"], torch.zeros(d.B, d.S), tb["actions"][:-1], torch.zeros(d.B, d.Be),
+                                 None, None, torch.tensor(noise["obs_prior"]), None)
+    assert pout[3] is None and pout[4] is None
+    for name, g_, w_ in zip(["prior-only beliefs", "prior-only states", "prior-only means", "prior-only stds"],
+                            [pout[0], pout[1], pout[2][0], pout[2][1]], [pwant[0], pwant[1], pwant[2][0], pwant[2][1]]):
+        assert_close(name, g_.cpu().numpy(), w_.numpy(), 2e-5, 2e-5)
     # imagine_ahead / get_action / heads / lambda_return
     from big_dreamer_amd.dreamer import lambda_return
     nz = {"action": cu(noise["action"]), "entropy": cu(noise["entropy"]), "img_prior": cu(noise["img_prior"])}
