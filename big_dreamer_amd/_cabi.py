@@ -111,7 +111,7 @@ _SIGS = {
     "bd_wgrad_grouped": (I32, [P, I32, I32, I32, P, P]),
     "bd_observe_forward": (I32, [C.POINTER(ObserveFwdArgs), P]),
     "bd_observe_backward": (I32, [C.POINTER(ObserveBwdArgs), P]),
-    "bd_observe_cluster_size": (I32, [I32]),
+    "bd_observe_cluster_size": (I32, [I32, I32]),
     "bd_observe_cluster_ws_floats": (C.c_size_t, [I32, I32]),
     "bd_observe_forward_cluster": (I32, [C.POINTER(ObserveFwdArgs), P, C.c_size_t, P]),
     "bd_observe_backward_cluster": (I32, [C.POINTER(ObserveBwdArgs), P, C.c_size_t, P]),

@@ -21,6 +21,7 @@
 // Residency: tiles*C <= 256 workgroups of one per CU are co-resident on an otherwise idle MI355X.
 #include "bd_device.h"
 #include "bd_host.h"
+#include <stdlib.h>
 
 namespace bd {
 
@@ -570,11 +571,14 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
     }
 }
 
-static int pick_cluster(int Be) {
-    const int Nb = cdiv(Be, 16);
-    int C = cdiv(Nb, kLocalBlocks);
+// Cluster size: one GRU column block per member while all tiles*Nb workgroups stay co-resident (measured best:
+// 13 CUs per tile at Be=200, B=50), else two blocks per member; 0 = not applicable (caller uses observe.hip).
+static int pick_cluster(int B, int Be) {
+    const int Nb = cdiv(Be, 16), tiles = cdiv(B, 16);
+    static const char* force2 = getenv("BD_OBS_CLUSTER_BLOCKS");      // tuning: "2" forces two blocks per member
+    int C = (tiles * Nb <= 256 && !(force2 && force2[0] == '2')) ? Nb : cdiv(Nb, kLocalBlocks);
     if (C < 1) C = 1;
-    return C <= kMaxCluster ? C : 0;    // 0: too wide for this variant -> caller uses the single-workgroup kernel
+    return (C <= kMaxCluster && tiles * C <= 256) ? C : 0;
 }
 
 static size_t scratch_floats_fwd() {
@@ -597,7 +601,7 @@ int bd_debug_cstamps(unsigned long long* out64) {
 }
 #endif
 
-int bd_observe_cluster_size(int Be) { return pick_cluster(Be); }
+int bd_observe_cluster_size(int B, int Be) { return pick_cluster(B, Be); }
 
 size_t bd_observe_cluster_ws_floats(int B, int Be) {
     const int tiles = cdiv(B, 16);
@@ -622,10 +626,9 @@ int bd_observe_forward_cluster(const bd_observe_fwd_args* a, float* ws, size_t w
                    a->w_hn && a->b_ih && a->b_hh && a->w_q1h && a->b_q1 && a->w_q2m && a->w_q2s && a->b_q2 &&
                    a->init_belief && a->init_state && a->actions && a->pre_emb && a->eps_post && a->feat &&
                    a->post_mean && a->post_std, "bd_observe_forward_cluster: missing pointers");
-    const int C = pick_cluster(a->Be);
-    BD_REQUIRE(C > 0, "bd_observe_forward_cluster: belief size %d too wide for the cluster variant", a->Be);
+    const int C = pick_cluster(a->B, a->Be);
+    BD_REQUIRE(C > 0, "bd_observe_forward_cluster: B=%d, Be=%d do not fit the cluster variant", a->B, a->Be);
     const int tiles = cdiv(a->B, 16);
-    BD_REQUIRE(tiles * C <= 256, "bd_observe_forward_cluster: %d workgroups would not be co-resident", tiles * C);
     BD_REQUIRE(ws_floats >= bd_observe_cluster_ws_floats(a->B, a->Be), "bd_observe_forward_cluster: workspace too small");
     const ObsDimsC d(a->Be, a->S, a->A, a->Hd);
     const size_t lds = ((size_t)(3 * d.Kb_h + d.Kb_hd + d.Kb_s + d.Kb_a) * kFragFloats + 16 * a->S + scratch_floats_fwd()) *
@@ -646,10 +649,9 @@ int bd_observe_backward_cluster(const bd_observe_bwd_args* a, float* ws, size_t 
                    a->wt_q2m && a->wt_q2s && a->init_belief && a->eps_post && a->feat && a->post_std && a->sv_x &&
                    a->sv_gates && a->sv_q && a->dfeat && a->d_embed_pre && a->d_gi && a->d_gh && a->d_q1_pre && a->d_q2_out,
                "bd_observe_backward_cluster: missing pointers");
-    const int C = pick_cluster(a->Be);
-    BD_REQUIRE(C > 0, "bd_observe_backward_cluster: belief size %d too wide for the cluster variant", a->Be);
+    const int C = pick_cluster(a->B, a->Be);
+    BD_REQUIRE(C > 0, "bd_observe_backward_cluster: B=%d, Be=%d do not fit the cluster variant", a->B, a->Be);
     const int tiles = cdiv(a->B, 16);
-    BD_REQUIRE(tiles * C <= 256, "bd_observe_backward_cluster: %d workgroups would not be co-resident", tiles * C);
     BD_REQUIRE(ws_floats >= bd_observe_cluster_ws_floats(a->B, a->Be), "bd_observe_backward_cluster: workspace too small");
     const ObsDimsC d(a->Be, a->S, a->A, a->Hd);
     const size_t lds = ((size_t)(6 * d.Kb_h + d.Kb_hd + 2 * d.Kb_s) * kFragFloats + 16 * a->S + scratch_floats_bwd()) *

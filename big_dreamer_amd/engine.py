@@ -145,7 +145,7 @@ class DreamerEngine:
         self._side = torch.cuda.Stream(device=self.dev)
         self._buf: Dict[str, torch.Tensor] = {}
         # cluster variant of the observe scan (several CUs per 16-row tile): on unless BD_OBS_CLUSTER=0
-        self.use_obs_cluster = os.environ.get("BD_OBS_CLUSTER", "1") != "0" and int(lib.bd_observe_cluster_size(d.Be)) > 0
+        self.use_obs_cluster = os.environ.get("BD_OBS_CLUSTER", "1") != "0"
         self._obs_ws: Optional[torch.Tensor] = None
         self._timers_on = False
         self._timer_events: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
@@ -427,7 +427,7 @@ class DreamerEngine:
         return feat, qm, qs
 
     def _cluster_ok(self, B: int) -> bool:
-        return self.use_obs_cluster and ((B + 15) // 16) * int(lib.bd_observe_cluster_size(self.d.Be)) <= 256
+        return self.use_obs_cluster and int(lib.bd_observe_cluster_size(B, self.d.Be)) > 0
 
     def _cluster_ws(self, B: int) -> torch.Tensor:
         need = int(lib.bd_observe_cluster_ws_floats(B, self.d.Be))

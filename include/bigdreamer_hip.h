@@ -180,13 +180,13 @@ typedef struct {
 } bd_observe_bwd_args;
 int bd_observe_backward(const bd_observe_bwd_args* a, void* stream);
 
-/* Cluster variant of the observe scan for small batches (B=50 -> only 4 row tiles): C = bd_observe_cluster_size(Be)
+/* Cluster variant of the observe scan for small batches (B=50 -> only 4 row tiles): C = bd_observe_cluster_size(B, Be)
  * workgroups (CUs) share each 16-row tile.  The GRU contraction is split by output column blocks over the members,
  * everything small is computed redundantly, and one all-gather per time step goes through `ws` (write-through
  * stores + per-member flags + sc1 loads, bounded spins).  Same arguments and results as bd_observe_forward /
  * bd_observe_backward; `ws` holds bd_observe_cluster_ws_floats(B, Be) floats and is zeroed (flags) by a memset
  * node on `stream` ahead of each launch.  bd_observe_cluster_status synchronises and reports a peer time-out. */
-int bd_observe_cluster_size(int Be);
+int bd_observe_cluster_size(int B, int Be);   /* workgroups per 16-row tile; 0 = use bd_observe_forward/backward */
 size_t bd_observe_cluster_ws_floats(int B, int Be);
 int bd_observe_forward_cluster(const bd_observe_fwd_args* a, float* ws, size_t ws_floats, void* stream);
 int bd_observe_backward_cluster(const bd_observe_bwd_args* a, float* ws, size_t ws_floats, void* stream);
