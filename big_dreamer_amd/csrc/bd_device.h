@@ -274,20 +274,37 @@ __device__ __forceinline__ void tile_linear_splitk(const Seg (&seg)[NSEG], const
     floatx4 acc[kSplitPairs];
 #pragma unroll
     for (int p = 0; p < kSplitPairs; ++p) acc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // A wave's share is tiny (<= 2 K blocks x <= 2 pairs per segment for K <= 16*kWaves): issue ALL its loads
+    // before the first MFMA, so the share costs one L2 round trip instead of one per (k block, pair).
+    constexpr int KW = 2;
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
         const int Kb = seg[s].Kb;
         const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(seg[s].X) + lane;
         const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(seg[s].W) + lane;
-        for (int kb = wave; kb < Kb; kb += kWaves) {
+        for (int kb0 = wave; kb0 < Kb; kb0 += kWaves * KW) {
+            floatx4 xa[KW][kSplitPairs], wb[KW][kSplitPairs];
 #pragma unroll
-            for (int p = 0; p < kSplitPairs; ++p) {
-                if (p < P) {
-                    const int nb = p / RT, rt = p - nb * RT;
-                    const floatx4 a4 = X4[(rt * Kb + kb) * 64];
-                    const floatx4 b4 = W4[((size_t)nb * Kb + kb) * 64];
+            for (int i = 0; i < KW; ++i) {
+                const int kb = kb0 + i * kWaves;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[p] = mfma16(a4[j], b4[j], acc[p]);
+                for (int p = 0; p < kSplitPairs; ++p) {
+                    if (kb < Kb && p < P) {
+                        const int nb = p / RT, rt = p % RT;
+                        xa[i][p] = X4[(rt * Kb + kb) * 64];
+                        wb[i][p] = W4[((size_t)nb * Kb + kb) * 64];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < KW; ++i) {
+                const int kb = kb0 + i * kWaves;
+#pragma unroll
+                for (int p = 0; p < kSplitPairs; ++p) {
+                    if (kb < Kb && p < P) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[p] = mfma16(xa[i][p][j], wb[i][p][j], acc[p]);
+                    }
                 }
             }
         }
@@ -377,23 +394,41 @@ __device__ __forceinline__ void tile_linear_dual_pre(const Seg2 (&seg)[NSEG], co
         floatx4 a0[kSplitPairs], a1[kSplitPairs];
 #pragma unroll
         for (int p = 0; p < kSplitPairs; ++p) a0[p] = a1[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+        constexpr int KW = 2;      // all loads of a wave's share first, then the MFMAs (see tile_linear_splitk)
 #pragma unroll
         for (int s = 0; s < NSEG; ++s) {
             const int Kb = seg[s].Kb;
             const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(seg[s].X) + lane;
             const floatx4* __restrict__ W0 = reinterpret_cast<const floatx4*>(seg[s].W0) + lane;
             const floatx4* __restrict__ W1 = reinterpret_cast<const floatx4*>(seg[s].W1) + lane;
-            for (int kb = wave; kb < Kb; kb += kWaves) {
-                const floatx4 x4 = X4[kb * 64];
+            for (int kb0 = wave; kb0 < Kb; kb0 += kWaves * KW) {
+                floatx4 xa[KW], pw[KW][kSplitPairs], qw[KW][kSplitPairs];
 #pragma unroll
-                for (int p = 0; p < kSplitPairs; ++p) {
-                    if (p < Nb) {
-                        const floatx4 p4 = W0[((size_t)p * Kb + kb) * 64], q4 = W1[((size_t)p * Kb + kb) * 64];
+                for (int i = 0; i < KW; ++i) {
+                    const int kb = kb0 + i * kWaves;
+                    if (kb < Kb) {
+                        xa[i] = X4[kb * 64];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            a0[p] = mfma16(x4[j], p4[j], a0[p]);
-                            a1[p] = mfma16(x4[j], q4[j], a1[p]);
-                        }
+                        for (int p = 0; p < kSplitPairs; ++p)
+                            if (p < Nb) {
+                                pw[i][p] = W0[((size_t)p * Kb + kb) * 64];
+                                qw[i][p] = W1[((size_t)p * Kb + kb) * 64];
+                            }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < KW; ++i) {
+                    const int kb = kb0 + i * kWaves;
+                    if (kb < Kb) {
+#pragma unroll
+                        for (int p = 0; p < kSplitPairs; ++p)
+                            if (p < Nb) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    a0[p] = mfma16(xa[i][j], pw[i][p][j], a0[p]);
+                                    a1[p] = mfma16(xa[i][j], qw[i][p][j], a1[p]);
+                                }
+                            }
                     }
                 }
             }

@@ -581,6 +581,15 @@ static int pick_cluster(int B, int Be) {
     return (C <= kMaxCluster && tiles * C <= 256) ? C : 0;
 }
 
+// The scan's members advance in lock step (one all-gather per time step), so a member that shares its CU's issue
+// slots with another stream's workgroups slows the whole cluster (measured under the engine's cross-step pipeline:
+// observe_bwd 1.0 -> 1.75 ms).  Requesting the CU's whole LDS keeps every LDS-using kernel of the other streams off
+// a member's CU.  BD_OBS_EXCLUSIVE=0 launches with the LDS the kernel needs.
+static size_t launch_lds(size_t need) {
+    static const char* e = getenv("BD_OBS_EXCLUSIVE");
+    return (e && e[0] == '0') ? need : (size_t)kMaxLds;
+}
+
 static size_t scratch_floats_fwd() {
     const size_t gru = (size_t)kWaves * kLocalBlocks * 4 * 64 * 4;
     return gru > (size_t)kSplitScratchFloats ? gru : (size_t)kSplitScratchFloats;
@@ -637,7 +646,8 @@ int bd_observe_forward_cluster(const bd_observe_fwd_args* a, float* ws, size_t w
     if (allow_big_lds(observe_cfwd_kernel)) return -1;
     if (hipMemsetAsync(ws, 0, cluster_ws_header_floats(tiles) * sizeof(float), (hipStream_t)stream) != hipSuccess)
         return fail("bd_observe_forward_cluster: memset failed");
-    hipLaunchKernelGGL(observe_cfwd_kernel, dim3(tiles * C), dim3(kThreads), lds, (hipStream_t)stream, *a, ws, C, tiles);
+    hipLaunchKernelGGL(observe_cfwd_kernel, dim3(tiles * C), dim3(kThreads), launch_lds(lds), (hipStream_t)stream, *a, ws, C,
+                       tiles);
     BD_CHECK_LAUNCH("bd_observe_forward_cluster");
     return 0;
 }
@@ -660,7 +670,8 @@ int bd_observe_backward_cluster(const bd_observe_bwd_args* a, float* ws, size_t 
     if (allow_big_lds(observe_cbwd_kernel)) return -1;
     if (hipMemsetAsync(ws, 0, cluster_ws_header_floats(tiles) * sizeof(float), (hipStream_t)stream) != hipSuccess)
         return fail("bd_observe_backward_cluster: memset failed");
-    hipLaunchKernelGGL(observe_cbwd_kernel, dim3(tiles * C), dim3(kThreads), lds, (hipStream_t)stream, *a, ws, C, tiles);
+    hipLaunchKernelGGL(observe_cbwd_kernel, dim3(tiles * C), dim3(kThreads), launch_lds(lds), (hipStream_t)stream, *a, ws, C,
+                       tiles);
     BD_CHECK_LAUNCH("bd_observe_backward_cluster");
     return 0;
 }

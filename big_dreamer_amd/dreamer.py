@@ -150,6 +150,7 @@ class Dreamer:
         """src/dreamer.py:179-237: (seq,batch,S), (seq,batch,Be) -> beliefs (H-1,N,Be), prior_states (H-1,N,S),
         (prior_means, prior_stds), action_entropy (H-1,N)."""
         e, d = self.engine, self.dims
+        e.join()
         N = prev_state.shape[0] * prev_state.shape[1]
         start = torch.cat([prev_belief.reshape(N, d.Be), prev_state.reshape(N, d.S)], dim=1).contiguous().float()
         Hm = self.planning_horizon - 1
@@ -169,6 +170,7 @@ class Dreamer:
         if deterministic:
             raise NotImplementedError("deterministic=True (SampleDist.mode) is never used by the reference loop")
         e, d = self.engine, self.dims
+        e.join()
         N = belief.shape[0]
         start = torch.cat([belief, state], dim=1).contiguous().float()
         noise = _noise or {"action": torch.randn(1, N, d.A, device=e.dev),

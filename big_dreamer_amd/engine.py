@@ -74,9 +74,7 @@ class WgradBatch:
     def __init__(self, eng: "DreamerEngine", name: str, ws_attr: str = "_wgrad_ws"):
         self.eng, self.name, self.ws_attr = eng, name, ws_attr
         self.items: List[tuple] = []
-        self._key = None
-        self._table = None
-        self._plan = (0, 0)
+        self._cache: Dict[tuple, tuple] = {}
 
     def add(self, dpre, ldp, act, lda, M, N, K, dW, ldw, db=None, act2=None, lda2=0, M1=None) -> None:
         self.items.append((ptr(dpre), ldp, ptr(act), lda, M if M1 is None else M1, ptr(act2), lda2, M, N, K, ptr(dW), ldw,
@@ -85,7 +83,8 @@ class WgradBatch:
     def run(self) -> None:
         eng = self.eng
         key = tuple(self.items)
-        if key != self._key:
+        hit = self._cache.get(key)
+        if hit is None:
             n = len(self.items)
             descs = (cabi.WgradDesc * n)()
             for i, it in enumerate(self.items):
@@ -93,13 +92,16 @@ class WgradBatch:
                  descs[i].M, descs[i].N, descs[i].K, descs[i].dW, descs[i].ldw, descs[i].db) = it
             tb, tr, wsf = C.c_int(0), C.c_int(0), C.c_size_t(0)
             cabi.check(lib.bd_wgrad_plan(descs, n, C.byref(tb), C.byref(tr), C.byref(wsf)))
-            self._table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(eng.dev)
-            self._plan = (n, tb.value, tr.value)
+            # (a pageable H2D copy synchronises with the device: tables are cached per operand-pointer set -- the
+            # double-buffered features and the replay's output ring make a handful of sets that then repeat)
+            table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(eng.dev)
             if getattr(eng, self.ws_attr).numel() < wsf.value:
                 setattr(eng, self.ws_attr, torch.zeros(wsf.value, dtype=torch.float32, device=eng.dev))
-            self._key = key
-        n, tb, tr = self._plan
-        cabi.check(lib.bd_wgrad_grouped(self._table.data_ptr(), n, tb, tr, ptr(getattr(eng, self.ws_attr)), cabi.stream()))
+            if len(self._cache) >= 16:
+                self._cache.pop(next(iter(self._cache)))
+            hit = self._cache[key] = (table, n, tb.value, tr.value)
+        table, n, tb, tr = hit
+        cabi.check(lib.bd_wgrad_grouped(table.data_ptr(), n, tb, tr, ptr(getattr(eng, self.ws_attr)), cabi.stream()))
         self.items = []
 
 
@@ -134,7 +136,7 @@ class DreamerEngine:
         self._wgrad_ws = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self._wgrad_ws_side = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.red_ws_side = torch.zeros(int(lib.bd_reduce_ws_floats()), dtype=torch.float32, device=self.dev)
-        self._wbatch = {"model": WgradBatch(self, "model"), "actor": WgradBatch(self, "actor"),
+        self._wbatch = {"model": WgradBatch(self, "model"), "actor": WgradBatch(self, "actor", "_wgrad_ws_bh"),
                         "critic": WgradBatch(self, "critic", "_wgrad_ws_side")}
         # The critic update only needs the imagined features and the lambda-returns, and the actor's backward pass uses
         # the critic TARGET: the two are independent, so the critic phase runs on a second HIP stream underneath the
@@ -143,11 +145,33 @@ class DreamerEngine:
         # by default (BD_OVERLAP_CRITIC=1 enables it; parity-tested either way).
         self.overlap_critic = os.environ.get("BD_OVERLAP_CRITIC", "0") == "1"
         self._side = torch.cuda.Stream(device=self.dev)
+        # Cross-step software pipeline (on unless BD_PIPELINE=0).  Dynamics learning of step k+1 reads only the world
+        # model that step k's model optimiser wrote, never what step k's behaviour learning (imagination, actor,
+        # critic) produces, while behaviour learning k needs the world model k and the posteriors k.  So the two
+        # halves run on two HIP streams: the latency-bound observe scan (52 CUs) of step k+1 runs underneath the
+        # imagination of step k (154 CUs) instead of leaving 200 CUs idle.  Same kernels, same operands, same order of
+        # every read-after-write: results are bit-identical to the serial schedule (parity-tested both ways).
+        #   s_wm:  [wait BH(k-1) done] encoder, observe fwd/bwd, heads, wgrad  [wait BH(k) done with the world model]
+        #          clip+Adam+pack -> ev_wm_done
+        #   s_bh:  [wait ev_wm_done] imagine fwd, heads, lambda-return -> ev_ret, imagine bwd -> ev_bh_wm_free; actor update
+        #          -> ev_bh_done
+        #   _side: [wait ev_ret] critic fwd/bwd, wgrad, clip+Adam+pack -> ev_cr_done  (under the next step's imagination)
+        # `feat` (posterior features, read by behaviour learning), the imagined features and the lambda-returns (read by
+        # the critic update) are double-buffered by step parity.
+        self.pipeline = os.environ.get("BD_PIPELINE", "1") != "0"
+        self._s_wm = torch.cuda.Stream(device=self.dev, priority=-1)   # the scan is latency-bound: dispatch it first
+        self._s_bh = torch.cuda.Stream(device=self.dev, priority=-1)   # the actor chain bounds the step; critic: _side
+        self._ev_bh_wm_free: Optional[torch.cuda.Event] = None
+        self._ev_bh_done: List[Optional[torch.cuda.Event]] = [None, None]
+        self._ev_cr_done: List[Optional[torch.cuda.Event]] = [None, None]
+        self._parity = 0
+        self._wgrad_ws_bh = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self.red_ws_bh = torch.zeros(int(lib.bd_reduce_ws_floats()), dtype=torch.float32, device=self.dev)
         self._buf: Dict[str, torch.Tensor] = {}
         # cluster variant of the observe scan (several CUs per 16-row tile): on unless BD_OBS_CLUSTER=0
         self.use_obs_cluster = os.environ.get("BD_OBS_CLUSTER", "1") != "0"
         self._obs_ws: Optional[torch.Tensor] = None
-        self._timers_on = False
+        self._timers_on, self._timer_every, self._timer_tick = False, 1, 0
         self._timer_events: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
         self._build_pack_tables()
         for g in ("model", "actor", "critic", "critic_target"):
@@ -161,21 +185,24 @@ class DreamerEngine:
             self.eng, self.name = eng, name
 
         def __enter__(self):
-            if self.eng._timers_on:
+            self.on = self.eng._timers_on and self.eng._timer_tick % self.eng._timer_every == 0
+            if self.on:
                 self.e0 = torch.cuda.Event(enable_timing=True)
                 self.e1 = torch.cuda.Event(enable_timing=True)
                 self.e0.record()
 
         def __exit__(self, *exc):
-            if self.eng._timers_on:
+            if self.on:
                 self.e1.record()
                 self.eng._timer_events.setdefault(self.name, []).append((self.e0, self.e1))
 
     def span(self, name: str) -> "DreamerEngine._Span":
         return DreamerEngine._Span(self, name)
 
-    def enable_timers(self, on: bool) -> None:
-        self._timers_on = on
+    def enable_timers(self, on: bool, every: int = 1) -> None:
+        """HIP-event spans around the kernel groups of every `every`-th train step (events cost queue slots and host
+        time, so a benchmark samples)."""
+        self._timers_on, self._timer_every, self._timer_tick = on, max(1, every), 0
         if on:
             self._timer_events = {}
 
@@ -335,6 +362,7 @@ class DreamerEngine:
 
     def update_critic(self) -> None:
         """polyak_update(critic_target, critic, polyak_avg) (src/dreamer.py:423-427)."""
+        self.join()
         t, s = self.groups["critic_target"], self.groups["critic"]
         cabi.check(lib.bd_polyak(ptr(t.flat), ptr(s.flat), t.numel, float(self.hp["polyak_avg"]), cabi.stream()))
         self.pack("critic_target")
@@ -389,7 +417,7 @@ class DreamerEngine:
         return x
 
     def observe(self, actions, nonterm, pre_emb, eps_post, init_belief, init_state, T: int, B: int, save: bool = True,
-                tag: str = "", prior_only: bool = False):
+                tag: str = "", prior_only: bool = False, feat_tag: str = ""):
         """TransitionModel.forward recurrence.  Returns feat [T*B x (Be+S)], mean, std of the fed-back state:
         the posterior (embeddings given) or, with prior_only=True (embeddings=None, src/models.py:241,296-297), the
         prior -- the same kernel run with the prior head's weights and a zero embedding projection."""
@@ -412,7 +440,7 @@ class DreamerEngine:
         a.init_belief, a.init_state, a.actions = ptr(init_belief), ptr(init_state), ptr(actions)
         a.nonterm, a.pre_emb, a.eps_post = ptr(nonterm), ptr(pre_emb), ptr(eps_post)
         a.min_std = self.hp["min_std_dev"]
-        feat = self.buf(tag + "feat", M, d.Be + d.S)
+        feat = self.buf(tag + feat_tag + "feat", M, d.Be + d.S)
         qm, qs = self.buf(tag + "post_mean", M, d.S), self.buf(tag + "post_std", M, d.S)
         a.feat, a.post_mean, a.post_std = ptr(feat), ptr(qm), ptr(qs)
         if save:
@@ -462,7 +490,7 @@ class DreamerEngine:
         self.mlp_forward(M, x, ldx, ldx, layers, acts + [None], out, out_width)
         return out, acts, layers
 
-    def imagine(self, start_feat, N: int, Hm: int, noise, save: bool = True, tag: str = ""):
+    def imagine(self, start_feat, N: int, Hm: int, noise, save: bool = True, tag: str = "", feat_tag: str = ""):
         d, pk = self.d, self.pk
         tm = lambda n: self.W("transition_model", n)
         ac = lambda n: self.W("actor", n)
@@ -485,7 +513,7 @@ class DreamerEngine:
         a.eps_action, a.eps_entropy, a.eps_prior = ptr(noise["action"]), ptr(noise["entropy"]), ptr(noise["img_prior"])
         a.min_std, a.act_raw_init_std = self.hp["min_std_dev"], ACT_RAW_INIT_STD
         a.act_min_std, a.act_mean_scale = ACT_MIN_STD, ACT_MEAN_SCALE
-        ifeat = self.buf(tag + "ifeat", Mi, d.Be + d.S)
+        ifeat = self.buf(tag + feat_tag + "ifeat", Mi, d.Be + d.S)
         a.feat = ptr(ifeat)
         a.prior_mean = ptr(self.buf(tag + "iprior_mean", Mi, d.S))
         a.prior_std = ptr(self.buf(tag + "iprior_std", Mi, d.S))
@@ -501,30 +529,78 @@ class DreamerEngine:
         return ifeat, ent, act
 
     # ------------------------------------------------------------------------------------------ train step
-    def make_noise(self, B: int) -> Dict[str, torch.Tensor]:
-        """On-device standard-normal noise for one step (perf mode; parity tests pass explicit arrays)."""
+    def make_noise(self, B: int, part: str = "all") -> Dict[str, torch.Tensor]:
+        """On-device standard-normal noise for one step (perf mode; parity tests pass explicit arrays), drawn on the
+        current stream.  part: "wm" (observe scan), "bh" (imagination) or "all"."""
         d = self.d
         T, N, Hm = d.T, d.T * B, d.Hm
-        shapes = dict(obs_prior=(T, B, d.S), obs_post=(T, B, d.S), action=(Hm, N, d.A),
-                      entropy=(Hm, d.n_entropy, N, d.A), img_prior=(Hm, N, d.S))
+        shapes = {}
+        if part in ("all", "wm"):
+            shapes.update(obs_prior=(T, B, d.S), obs_post=(T, B, d.S))
+        if part in ("all", "bh"):
+            shapes.update(action=(Hm, N, d.A), entropy=(Hm, d.n_entropy, N, d.A), img_prior=(Hm, N, d.S))
         return {k: self.buf("noise_" + k, *s).normal_() for k, s in shapes.items()}
+
+    def join(self) -> None:
+        """Order everything the pipeline streams have been given before later work on the caller's stream."""
+        if self.pipeline:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._s_wm)
+            cur.wait_stream(self._s_bh)
+            cur.wait_stream(self._side)
 
     def train_step(self, batch: Dict[str, torch.Tensor], noise: Optional[Dict[str, torch.Tensor]] = None,
                    sync_logs: bool = True) -> Dict[str, float]:
         """One Dreamer.train_step (src/dreamer.py:253-393) on this rank's batch shard.
 
         batch: observations (L,B,O), actions (L,B,A), rewards (L,B), nonterminals (L,B,1) -- device fp32,
-        contiguous, time-major as ExperienceReplay.sample returns them (src/memory.py:87-104)."""
+        contiguous, time-major as ExperienceReplay.sample returns them (src/memory.py:87-104).
+        With the pipeline on, the two halves are queued on the engine's own streams and the call returns without
+        ordering them against the caller's stream; `logs()` / `join()` do that (sync_logs=True calls logs())."""
+        obs = batch["observations"]
+        B = obs.shape[1]
+        self._timer_tick += 1
+        if not self.pipeline:
+            if noise is None:
+                noise = self.make_noise(B)
+            feat = self._dynamics_phase(batch, noise, "")
+            self._behaviour_phase(feat, noise, obs.shape[0] - 1, B, self.red_ws, None)
+            return self.logs() if sync_logs else {}
+        cur = torch.cuda.current_stream()
+        s_wm, s_bh = self._s_wm, self._s_bh
+        par = self._parity
+        self._parity ^= 1
+        s_wm.wait_stream(cur)                       # the batch (and explicit noise) were produced on the caller's stream
+        for t in batch.values():
+            t.record_stream(s_wm)
+        if noise is not None:
+            for t in noise.values():
+                t.record_stream(s_wm)
+                t.record_stream(s_bh)
+        with torch.cuda.stream(s_wm):
+            if self._ev_bh_done[par] is not None:   # feat[par] was last read by behaviour learning two steps ago
+                s_wm.wait_event(self._ev_bh_done[par])
+            nz = noise if noise is not None else self.make_noise(B, "wm")
+            feat = self._dynamics_phase(batch, nz, f"p{par}_")
+            ev_wm_done = torch.cuda.Event()
+            ev_wm_done.record(s_wm)
+        with torch.cuda.stream(s_bh):
+            s_bh.wait_event(ev_wm_done)
+            nz = noise if noise is not None else self.make_noise(B, "bh")
+            self._behaviour_phase(feat, nz, obs.shape[0] - 1, B, self.red_ws_bh, par)
+            self._ev_bh_done[par] = torch.cuda.Event()
+            self._ev_bh_done[par].record(s_bh)
+        return self.logs() if sync_logs else {}
+
+    def _dynamics_phase(self, batch: Dict[str, torch.Tensor], noise: Dict[str, torch.Tensor], feat_tag: str) -> torch.Tensor:
+        """Dynamics learning (src/dreamer.py:263-302) on the current stream; returns the posterior features."""
         d, hp = self.d, self.hp
         obs, actions, rewards, nonterm = (batch[k] for k in ("observations", "actions", "rewards", "nonterminals"))
         L, B = obs.shape[0], obs.shape[1]
-        T, Hm = L - 1, d.Hm
+        T = L - 1
         N = T * B
-        Mi = Hm * N
         F = d.Be + d.S
         W = self.world_size
-        if noise is None:
-            noise = self.make_noise(B)
         st = cabi.stream()
         sc, ws = ptr(self.scalars), ptr(self.red_ws)
 
@@ -534,7 +610,8 @@ class DreamerEngine:
             emb, pre_emb = self.encode_pixels(obs[1:].reshape(N, 3, 64, 64)) if self.pixel else self.encode(obs_t, N)
         init_belief = self.buf("init_belief", B, d.Be).zero_()
         init_state = self.buf("init_state", B, d.S).zero_()
-        feat, qm, qs = self.observe(actions[:-1], nonterm[:-1], pre_emb, noise["obs_post"], init_belief, init_state, T, B)
+        feat, qm, qs = self.observe(actions[:-1], nonterm[:-1], pre_emb, noise["obs_post"], init_belief, init_state, T, B,
+                                    feat_tag=feat_tag)
         with self.span("wm_heads_fwd"):
             _, pm, ps = self.prior_head(feat, N, noise["obs_prior"])
             if self.pixel:
@@ -649,21 +726,49 @@ class DreamerEngine:
             self._dense_wgrads(wb, "encoder", N, enc_dpre, obs_t, d.O, enc_acts, dense_sizes(d.O, d.E))
         with self.span("wgrad_model"):
             wb.run()
+        if self.pipeline and self._ev_bh_wm_free is not None:
+            # the previous step's imagination / reward-head kernels may still be reading the weights Adam overwrites
+            torch.cuda.current_stream().wait_event(self._ev_bh_wm_free)
         with self.span("opt_model"):
             self.optimizer_step("model", SLOT_GN_MODEL, hp["model_learning_rate"])
+        return feat
 
-        # ======================= behaviour learning (dreamer.py:308-367) =======================
-        # imagination uses the post-update world model (packed by optimizer_step) and detached posteriors
-        ifeat, ent, act = self.imagine(feat, N, Hm, noise)
+    def _behaviour_phase(self, feat: torch.Tensor, noise: Dict[str, torch.Tensor], T: int, B: int,
+                         red_ws: torch.Tensor, par: Optional[int]) -> None:
+        """Behaviour learning (src/dreamer.py:308-391) on the current stream: imagination with the post-update world
+        model (packed by the model optimiser step) from the detached posteriors, actor update, critic update."""
+        d, hp, pk = self.d, self.hp, self.pk
+        Hm = d.Hm
+        N = T * B
+        Mi = Hm * N
+        F = d.Be + d.S
+        st = cabi.stream()
+        sc, ws = ptr(self.scalars), ptr(red_ws)
+        sum_form = int(hp["kl_balance"] == -1)
+        # Pipelined (par = step parity): the critic update of this step runs on a third stream underneath the NEXT
+        # step's imagination (it only needs the imagined features and the lambda-returns, and nothing on the actor's
+        # chain reads the critic -- the value head there is the critic TARGET), so both are double-buffered by parity.
+        ptag = "" if par is None else f"p{par}_"
+        if par is not None and self._ev_cr_done[par] is not None:
+            torch.cuda.current_stream().wait_event(self._ev_cr_done[par])     # critic of two steps ago: last reader
+        ifeat, ent, act = self.imagine(feat, N, Hm, noise, feat_tag=ptag)
         with self.span("img_heads_fwd"):
             r_out, r_acts, r_layers = self.dense_forward("reward_model", "rew", "ir", ifeat, F, Mi, 1)
             v_out, v_acts, v_layers = self.dense_forward("critic_target", "tgt", "iv", ifeat, F, Mi, 1)
-        returns = self.buf("returns", Mi)
+        returns = self.buf(ptag + "returns", Mi)
         cabi.check(lib.bd_lambda_return_forward(ptr(r_out), ptr(v_out), Hm, N, hp["discount"], hp["disclam"], ptr(returns), st))
         cabi.check(lib.bd_sum(ptr(returns), Mi, sc, SLOT_RET, ws, st))
         cabi.check(lib.bd_sum(ptr(ent), Mi, sc, SLOT_ENT, ws, st))
         inv_mi = self.dp.mean_grad_scale(Mi)
-        if self.overlap_critic:      # fork: critic phase on the side stream, actor backward continues here
+        if par is not None:
+            ev_ret = torch.cuda.Event()
+            ev_ret.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev_ret)
+                self._critic_phase(ifeat, returns, Mi, F, inv_mi, self.red_ws_side)
+                self._ev_cr_done[par] = torch.cuda.Event()
+                self._ev_cr_done[par].record(self._side)
+        elif self.overlap_critic:    # fork: critic phase on the side stream, actor backward continues here
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
                 self._critic_phase(ifeat, returns, Mi, F, inv_mi, self.red_ws_side)
@@ -694,6 +799,9 @@ class DreamerEngine:
         c.d_actor_pre, c.d_actor_out = ptr(d_apre), ptr(d_aout)
         with self.span("imagine_bwd"):
             cabi.check(lib.bd_imagine_backward(C.byref(c), st))
+        if self.pipeline:       # last reader of the world model in this step
+            self._ev_bh_wm_free = torch.cuda.Event()
+            self._ev_bh_wm_free.record(torch.cuda.current_stream())
         Ga = lambda n: self.G("actor", n)
         wa = self._wbatch["actor"]
         # layer 0 input = [h_t; s_t]: start features for t = 0 (rows < N), imagined features of step t-1 afterwards
@@ -706,15 +814,15 @@ class DreamerEngine:
         with self.span("wgrad_actor"):
             wa.run()
         with self.span("opt_actor"):
-            self.optimizer_step("actor", SLOT_GN_ACTOR, hp["actor_learning_rate"])
+            self.optimizer_step("actor", SLOT_GN_ACTOR, hp["actor_learning_rate"], red_ws)
 
-        if not self.overlap_critic:
-            self._critic_phase(ifeat, returns, Mi, F, inv_mi, self.red_ws)
+        if par is not None:
+            pass
+        elif not self.overlap_critic:
+            self._critic_phase(ifeat, returns, Mi, F, inv_mi, red_ws)
         else:
             torch.cuda.current_stream().wait_stream(self._side)     # join before the next step reuses ifeat / returns
-
         self._counts = dict(N=N, Mi=Mi, S=d.S, sum_form=sum_form)
-        return self.logs() if sync_logs else {}
 
     def _critic_phase(self, ifeat, returns, Mi: int, F: int, inv_mi: float, red_ws: torch.Tensor) -> None:
         """Critic update (src/dreamer.py:370-391) on the current stream: forward on the detached imagined features,
@@ -737,6 +845,7 @@ class DreamerEngine:
     def logs(self) -> Dict[str, float]:
         """One D2H copy of the scalar board -> the reference's log dict (src/dreamer.py:293-296,359-360,383).
         Values are this rank's shard means (fp32 arithmetic as in the reference)."""
+        self.join()
         s = self.scalars.cpu().numpy().astype(np.float32)
         hp, c = self.hp, self._counts
         f32 = np.float32

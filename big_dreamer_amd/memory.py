@@ -30,6 +30,7 @@ class ExperienceReplay:
         self.steps, self.episodes = 0, 0
         self._dev = None          # device mirror, created lazily / refreshed by sync_device()
         self._dirty = True
+        self._out_ring, self._out_i = {}, {}
         self._ring = []           # pinned staging buffers for the index upload (async H2D, no host stall)
         self._ring_i = 0
 
@@ -91,6 +92,18 @@ class ExperienceReplay:
         ev.record()
         return dev
 
+    def _out(self, key: str, numel: int) -> torch.Tensor:
+        """Output buffers come from a ring of four persistent allocations per array, so that the kernels downstream
+        see a small repeating set of operand addresses (descriptor tables and graphs can be reused) while a batch
+        stays valid for the next three `sample` calls -- the engine's pipeline holds one for at most two."""
+        ring = self._out_ring.setdefault((key, numel), [])
+        if len(ring) < 4:
+            ring.append(torch.empty(numel, dtype=torch.float32, device=self.device))
+            return ring[-1]
+        i = self._out_i.get((key, numel), 0)
+        self._out_i[(key, numel)] = (i + 1) % 4
+        return ring[i]
+
     def sample(self, n, L):
         """Time-major batch [obs (L,n,O), actions (L,n,A), rewards (L,n), nonterminals (L,n,1)] on the device
         (src/memory.py:70-104)."""
@@ -116,7 +129,7 @@ class ExperienceReplay:
                 continue
             src = self._dev[key]
             width = src.numel() // src.shape[0]
-            dst = torch.empty(L * n * width, dtype=torch.float32, device=self.device)
+            dst = self._out(key, L * n * width)
             cabi.check(cabi.lib.bd_replay_gather(src.data_ptr(), vidx.data_ptr(), L * n, width, dst.data_ptr(),
                                                  cabi.stream()))
             out.append(dst.view(*shape))

@@ -58,6 +58,7 @@ class DenseModel(_EngineBacked):
         self._bind(engine, module, group)
 
     def forward(self, *args: Tensor) -> Tensor:
+        self._eng.join()      # order after any queued pipeline work (engine.train_step)
         x = torch.cat(args, dim=-1) if len(args) == 2 else args[0]
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self._in).contiguous().float()
@@ -102,6 +103,7 @@ class TransitionModel(_EngineBacked):
                 nonterminals: Optional[Tensor] = None, _noise: Optional[Tuple[Tensor, Tensor]] = None):
         """init_state (B,S), actions (T,B,A), init_belief (B,Be), embeddings (T,B,E), nonterminals (T,B,1) ->
         beliefs (T,B,Be), prior_states, (prior_means, prior_stds), posterior_states, (post_means, post_stds)."""
+        self._eng.join()      # order after any queued pipeline work (engine.train_step)
         eng = self._eng
         Be, S, A, Hd, E = self._dims
         T, B = actions.shape[0], actions.shape[1]
@@ -165,6 +167,7 @@ class CnnImageEncoder(_EngineBacked):
 
     @torch.no_grad()
     def forward(self, observation: Tensor) -> Tensor:
+        self._eng.join()      # order after any queued pipeline work (engine.train_step)
         lead = observation.shape[:-3]
         emb, _ = self._eng.encode_pixels(observation.reshape(-1, 3, 64, 64).contiguous().float(), grad=False)
         return emb.view(*lead, -1).clone()
@@ -186,6 +189,7 @@ class ObservationModel(_EngineBacked):
 
     @torch.no_grad()
     def forward(self, belief: Tensor, state: Tensor) -> Tensor:
+        self._eng.join()      # order after any queued pipeline work (engine.train_step)
         lead = belief.shape[:-1]
         x = torch.cat([belief, state], dim=-1).reshape(-1, belief.shape[-1] + state.shape[-1]).contiguous().float()
         return self._eng.decode_pixels(x, grad=False).view(*lead, 3, 64, 64).clone()
