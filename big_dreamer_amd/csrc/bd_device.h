@@ -34,6 +34,18 @@ __device__ __forceinline__ floatx4 mfma16(float a, float b, floatx4 c) {
 
 __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// threadIdx.x behind an opaque move.  hipcc hoists everything that depends only on the thread index -- per-lane 64-bit
+// weight pointers of ~30 matrices, row / column indices and output addresses of every epilogue -- out of the
+// persistent kernels' time loops and then SPILLS it (60-68 VGPRs at 8 waves per workgroup): each reload inside a
+// step is a scratch load behind s_waitcnt vmcnt(0), i.e. a full memory round trip on the critical path (the
+// Gaussian-head phases spent 3-4k cycles on eight of them, s_memtime stamps).  A fresh opaque value per primitive
+// call / per time step keeps that arithmetic (a handful of VALU instructions) inside the phase that uses it.
+__device__ __forceinline__ int bd_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc emit s_waitcnt vmcnt(0), and
 // on CDNA4 vmcnt counts global STORES too: every phase of a persistent kernel would wait for its
 // saved-activation stores to be acknowledged by L2.  The tile kernels hand data between phases through LDS
@@ -50,13 +62,31 @@ __device__ __forceinline__ int frag_idx(int row, int k) {
     return ((k >> 4) * 64 + ((k >> 2) & 3) * 16 + row) * 4 + (k & 3);
 }
 
-// ---- math (matching torch CPU fp32 semantics) ---------------------------------------------------
+// ---- math ----------------------------------------------------------------------------------------
+// The activation epilogues sit on the critical path of every phase of the persistent kernels (one wave finishes
+// its column blocks, then runs 8 transcendental chains before the workgroup barrier): libm-grade expm1f / log1pf /
+// tanhf cost 2-3k cycles per phase (s_memtime stamps), a quarter of a 200x200 layer.  These forms use the hardware
+// v_exp_f32 / v_log_f32 / v_rcp_f32 (1 ulp) instead.  Their ABSOLUTE error is <= ~2e-7 for outputs of magnitude
+// <= 1 (ELU's negative branch, sigmoid, tanh) and for softplus, which is what the stated fp32 tolerance (2e-5 abs/rel
+// on forward tensors) is about; they lose RELATIVE accuracy only where the result itself is ~1e-7.
+// -DBD_EXACT_MATH restores the libm forms (matching torch CPU fp32 to the last bits).
+#ifdef BD_EXACT_MATH
 __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : expm1f(x); }
-// derivative of ELU expressed through its output y (y<=0 <=> x<=0): 1 or exp(x) = y+1
-__device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float tanh_act(float x) { return tanhf(x); }
 // F.softplus(beta=1, threshold=20)
 __device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+// 1 - exp(-x), x >= 0  (= sigmoid(raw) when x = softplus(raw))
+__device__ __forceinline__ float one_minus_exp_neg(float x) { return -expm1f(-x); }
+#else
+__device__ __forceinline__ float elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
+__device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_act(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
+__device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : __logf(1.f + __expf(x)); }
+__device__ __forceinline__ float one_minus_exp_neg(float x) { return 1.f - __expf(-x); }
+#endif
+// derivative of ELU expressed through its output y (y<=0 <=> x<=0): 1 or exp(x) = y+1
+__device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
 __device__ __forceinline__ float act_apply(int act, float x) { return act ? elu(x) : x; }
 
 // ---- reductions ------------------------------------------------------------------------------------
@@ -73,12 +103,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // sum over the workgroup; result valid in thread 0.  `red` = kWaves doubles of LDS.
 __device__ __forceinline__ double block_sum_d(double v, double* red) {
     v = wave_sum_d(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = bd_tid() & 63, wave = bd_tid() >> 6;
     __syncthreads();
     if (lane == 0) red[wave] = v;
     __syncthreads();
     double s = 0.0;
-    if (threadIdx.x == 0) {
+    if (bd_tid() == 0) {
         const int nw = (blockDim.x + 63) >> 6;
         for (int w = 0; w < nw; ++w) s += red[w];
     }
@@ -94,7 +124,7 @@ __device__ __forceinline__ void load_tile_concat(float* __restrict__ X, int Kb, 
                                                  const float* __restrict__ in1, int ld1, int w1,
                                                  float scale = 1.f) {
     const int Kp = Kb * 16;
-    for (int idx = threadIdx.x; idx < RT * 16 * Kp; idx += blockDim.x) {
+    for (int idx = bd_tid(); idx < RT * 16 * Kp; idx += blockDim.x) {
         const int r = idx / Kp, k = idx - r * Kp;
         const int grow = row0 + r;
         float v = 0.f;
@@ -191,7 +221,7 @@ struct NoPre {
 template <int NSEG, int RT, int NI, int D, class Pre, class Epi>
 __device__ __forceinline__ void linear_blocks(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, int nb0,
                                               Pre&& pre, Epi&& epi) {
-    const int lane = threadIdx.x & 63;
+    const int lane = bd_tid() & 63;
     decltype(pre(0, 0)) pf[NI][RT];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -246,6 +276,18 @@ __device__ __forceinline__ void linear_blocks(const Seg (&seg)[NSEG], const floa
         for (int rt = 0; rt < RT; ++rt) epi(rt, nb0 + i * kWaves, acc[i][rt], pf[i][rt]);
 }
 
+// Diagnostic build only (-DBD_STAMPS): s_memtime at points inside a tile primitive, recorded by thread 0 of workgroup 0
+// when the caller passes a slot base >= 0 (each translation unit has its own table).  Never in the shipped .so.
+#ifdef BD_STAMPS
+static __device__ unsigned long long g_dstamps[64];
+#define BD_DSTAMP(base, k)                                                                                  \
+    do {                                                                                                    \
+        if ((base) >= 0 && blockIdx.x == 0 && threadIdx.x == 0) g_dstamps[(base) + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define BD_DSTAMP(base, k)
+#endif
+
 // ---- split-K over waves for narrow outputs ----------------------------------------------------------------
 // When a layer has at most two (column block, row tile) pairs (N <= 32: the mean/std heads, the N=1 heads of the
 // reward/value chains, the d/d(state|action) of the embed layer) the column-block decomposition leaves all but
@@ -254,12 +296,15 @@ __device__ __forceinline__ void linear_blocks(const Seg (&seg)[NSEG], const floa
 // scratch ([kWaves][pairs][64 lanes] float4) and the first `pairs` waves sum them in fixed order (deterministic)
 // and run the epilogue.  Costs one extra barrier, removes ~Kb/kWaves round trips from the step's critical path.
 constexpr int kSplitPairs = 2;
-constexpr int kSplitScratchFloats = kWaves * kSplitPairs * 2 * kFragFloats;   // dual form needs 2 outputs per pair
+constexpr int kHeadMaxN = 64;                                   // widest Gaussian head tile_dual_head_elem spreads
+constexpr int kHeadPlainFloats = 2 * 16 * kHeadMaxN;            // [2][16 rows][<= 64 columns] behind the partials
+constexpr int kSplitPartialFloats = kWaves * kSplitPairs * 2 * kFragFloats;   // dual form needs 2 outputs per pair
+constexpr int kSplitScratchFloats = kSplitPartialFloats + kHeadPlainFloats;
 
 template <int RT, int NSEG, class Pre, class Epi>
 __device__ __forceinline__ void tile_linear_splitk(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
                                                    float* __restrict__ scratch, Pre&& pre, Epi&& epi) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = bd_tid() & 63, wave = bd_tid() >> 6;
     const int Nb = (N + 15) >> 4;
     const int P = Nb * RT;                      // <= kSplitPairs (checked by the caller)
     // the reducing waves fetch their bias and epilogue operands up front
@@ -327,7 +372,7 @@ __device__ __forceinline__ void tile_linear_splitk(const Seg (&seg)[NSEG], const
 template <int RT, int NSEG, class Pre, class Epi>
 __device__ __forceinline__ void tile_linear_pre(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Pre&& pre,
                                                 Epi&& epi, float* __restrict__ scratch = nullptr) {
-    const int wave = threadIdx.x >> 6;
+    const int wave = bd_tid() >> 6;
     const int Nb = (N + 15) >> 4;
     if (scratch != nullptr && Nb * RT <= kSplitPairs) {   // workgroup-uniform
         tile_linear_splitk<RT, NSEG>(seg, bias, N, scratch, pre, epi);
@@ -379,10 +424,11 @@ struct DualFrag {
 template <int NSEG, class Pre, class Epi>
 __device__ __forceinline__ void tile_linear_dual_pre(const Seg2 (&seg)[NSEG], const float* __restrict__ bias0,
                                                      const float* __restrict__ bias1, int N, Pre&& pre, Epi&& epi,
-                                                     float* __restrict__ scratch = nullptr) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                     float* __restrict__ scratch = nullptr, int sb = -1) {
+    const int lane = bd_tid() & 63, wave = bd_tid() >> 6;
     const int Nb = (N + 15) >> 4;
     if (scratch != nullptr && Nb <= kSplitPairs) {   // split-K over waves (see tile_linear_splitk); both W0, W1 given
+        BD_DSTAMP(sb, 0);
         decltype(pre(0)) pf{};
         float mb0 = 0.f, mb1 = 0.f;
         if (wave < Nb) {                              // reducing waves: bias + epilogue operands up front
@@ -433,6 +479,7 @@ __device__ __forceinline__ void tile_linear_dual_pre(const Seg2 (&seg)[NSEG], co
                 }
             }
         }
+        BD_DSTAMP(sb, 1);
         floatx4* __restrict__ S4 = reinterpret_cast<floatx4*>(scratch);
 #pragma unroll
         for (int p = 0; p < kSplitPairs; ++p)
@@ -440,14 +487,18 @@ __device__ __forceinline__ void tile_linear_dual_pre(const Seg2 (&seg)[NSEG], co
                 S4[((wave * kSplitPairs + p) * 2 + 0) * 64 + lane] = a0[p];
                 S4[((wave * kSplitPairs + p) * 2 + 1) * 64 + lane] = a1[p];
             }
+        BD_DSTAMP(sb, 2);
         lds_barrier();
+        BD_DSTAMP(sb, 3);
         if (wave < Nb) {
             floatx4 r0 = floatx4{mb0, mb0, mb0, mb0}, r1 = floatx4{mb1, mb1, mb1, mb1};
             for (int w = 0; w < kWaves; ++w) {
                 r0 += S4[((w * kSplitPairs + wave) * 2 + 0) * 64 + lane];
                 r1 += S4[((w * kSplitPairs + wave) * 2 + 1) * 64 + lane];
             }
+            BD_DSTAMP(sb, 4);
             epi(wave, r0, r1, pf);
+            BD_DSTAMP(sb, 5);
         }
         return;
     }
@@ -503,6 +554,59 @@ __device__ __forceinline__ void tile_linear_dual(const Seg2 (&seg)[NSEG], const 
                                [&](int nb, floatx4 a0, floatx4 a1, NoPreVal) { epi(nb, a0, a1); }, scratch);
 }
 
+// Gaussian head with an ELEMENT-wise epilogue.  tile_linear_dual_pre hands each (mean, raw) accumulator to the wave
+// that reduced it: for a narrow head that is one or two waves running 4 rows x (softplus, tanh, ...) chains per lane
+// back to back while the other waves wait (12k cycles of the 18k-cycle actor head, s_memtime stamps).  Here the
+// reduced pre-activations go to LDS ([2][16][16*Nb] behind the split-K partials), and after one more barrier every
+// thread finishes ONE (row, column) element: pre_elem(row, col) fetches its streamed operand (noise) before the
+// contraction, epi_elem(row, col, mean_pre, raw_pre, operand) does the math and the stores.  N <= kHeadMaxN.
+template <int NSEG, class PreE, class EpiE>
+__device__ __forceinline__ void tile_dual_head_elem(const Seg2 (&seg)[NSEG], const float* __restrict__ bias0,
+                                                    const float* __restrict__ bias1, int N, float* __restrict__ scratch,
+                                                    PreE&& pre_elem, EpiE&& epi_elem, int sb = -1) {
+    const int lane = bd_tid() & 63;
+    const int Nb = (N + 15) >> 4, Np = Nb * 16;
+    float* __restrict__ plain = scratch + kSplitPartialFloats;
+    const int e0 = bd_tid();
+    const int row0e = e0 / N, col0e = e0 - row0e * N;
+    decltype(pre_elem(0, 0)) pv{};
+    BD_DSTAMP(sb, 0);
+#ifdef BD_STAMPS
+    if (sb >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // diagnostic: drain what the earlier phases left in flight
+    BD_DSTAMP(sb, 6);
+#endif
+    if (e0 < 16 * N) pv = pre_elem(row0e, col0e);
+#ifdef BD_STAMPS
+    if (sb >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // diagnostic: latency of the operand load alone
+    BD_DSTAMP(sb, 7);
+#endif
+    BD_DSTAMP(sb, 1);
+    tile_linear_dual_pre<NSEG>(
+        seg, bias0, bias1, N, NoPre1{},
+        [&](int nb, floatx4 a0, floatx4 a1, NoPreVal) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (4 * (lane >> 4) + r) * Np + nb * 16 + (lane & 15);
+                plain[o] = a0[r];
+                plain[16 * Np + o] = a1[r];
+            }
+        },
+        Nb <= kSplitPairs ? scratch : nullptr, sb >= 0 ? sb + 16 : -1);
+    BD_DSTAMP(sb, 2);
+    lds_barrier();
+    BD_DSTAMP(sb, 3);
+#ifdef BD_STAMPS
+    if (sb >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // diagnostic: separate the operand wait from the math
+    BD_DSTAMP(sb, 4);
+#endif
+    if (e0 < 16 * N) epi_elem(row0e, col0e, plain[row0e * Np + col0e], plain[16 * Np + row0e * Np + col0e], pv);
+    BD_DSTAMP(sb, 5);
+    for (int e = e0 + blockDim.x; e < 16 * N; e += blockDim.x) {
+        const int row = e / N, col = e - row * N;
+        epi_elem(row, col, plain[row * Np + col], plain[16 * Np + row * Np + col], pre_elem(row, col));
+    }
+}
+
 // ---- GRU cell (nn.GRUCell, src/models.py:149,252): four accumulators per output column block ----------
 //   R  = W_ir x + W_hr h + b_ir + b_hr      Z  = W_iz x + W_hz h + b_iz + b_hz
 //   NI = W_in x + b_in                      NH = W_hn h + b_hn
@@ -519,7 +623,7 @@ struct GruFrag {
 template <class Epi>
 __device__ __forceinline__ void gru_tile(const float* __restrict__ X, const float* __restrict__ Hf, int Kb, int Be,
                                          const GruW& w, Epi&& epi) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = bd_tid() & 63, wave = bd_tid() >> 6;
     const int Nb = (Be + 15) >> 4;
     const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(X) + lane;
     const floatx4* __restrict__ H4 = reinterpret_cast<const floatx4*>(Hf) + lane;
@@ -573,7 +677,7 @@ template <class Pre, class Epi>
 __device__ __forceinline__ void gru_tile_bwd(const float* __restrict__ dR, const float* __restrict__ dZ,
                                              const float* __restrict__ dNI, const float* __restrict__ dNH, int Kb,
                                              int Be, const GruWT& w, Pre&& pre, Epi&& epi) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = bd_tid() & 63, wave = bd_tid() >> 6;
     const int Nb = (Be + 15) >> 4;
     const floatx4* __restrict__ R4 = reinterpret_cast<const floatx4*>(dR) + lane;
     const floatx4* __restrict__ Z4 = reinterpret_cast<const floatx4*>(dZ) + lane;

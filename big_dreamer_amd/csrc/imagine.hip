@@ -133,7 +133,6 @@ struct PreAct {          // operands of the action-sample backward per accumulat
 __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ImgDims d(a.Be, a.S, a.A, a.Hd);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = blockIdx.x * 16;
     const int F = a.Be + a.S, A = a.A;
     const int nh = d.Kb_h * kFragFloats, nhd = d.Kb_hd * kFragFloats;
@@ -152,19 +151,21 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
 
     load_tile_concat<1>(h_cur, d.Kb_h, row0, a.N, a.start_feat, F, a.Be, nullptr, 0, 0);
     load_tile_concat<1>(sf, d.Kb_s, row0, a.N, a.start_feat + a.Be, F, a.S, nullptr, 0, 0);
+    for (int i = threadIdx.x; i < d.Kb_a * kFragFloats; i += blockDim.x) af[i] = 0.f;   // columns >= A stay zero
     lds_barrier();
 
     const GruW gw{a.w_ir, a.w_iz, a.w_in, a.w_hr, a.w_hz, a.w_hn, a.b_ih, a.b_hh};
     const size_t act_stride = (size_t)a.Hm * a.N * a.Hd;
     const float inv_ns = 1.f / (float)a.n_samples;
 
-    // hidden layer epilogue: ELU -> LDS fragment (+ optional save)
-    auto hidden_epi = [&](float* dst, float* save, size_t tn, int width) {
-        return HiddenEpi{dst, save, tn, width, a.N, row0, lane};
-    };
-
     for (int t = 0; t < a.Hm; ++t) {
         const size_t tn = (size_t)t * a.N;
+        const int tid = bd_tid();                   // opaque: nothing thread-dependent leaves this step (bd_tid)
+        const int lane = tid & 63, wave = tid >> 6;
+        // hidden layer epilogue: ELU -> LDS fragment (+ optional save)
+        auto hidden_epi = [&](float* dst, float* save, size_t tn_, int width) {
+            return HiddenEpi{dst, save, tn_, width, a.N, row0, lane};
+        };
         BD_STAMP(0);
         // ---- actor hidden layers ----
         {
@@ -190,50 +191,37 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         // ---- actor output, action sample ----
         {
             const Seg2 segs[1] = {{bufB, a.w_a4m, a.w_a4s, d.Kb_hd}};
-            tile_linear_dual_pre<1>(
-                segs, a.b_a4, a.b_a4 + A, A,
-                [&](int nb) {
-                    Pre4 p;
-                    const int col = nb * 16 + (lane & 15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int grow = row0 + 4 * (lane >> 4) + r;
-                        p.v[r] = (grow < a.N && col < A) ? a.eps_action[(tn + grow) * A + col] : 0.f;
-                    }
-                    return p;
-                },
-                [&](int nb, floatx4 Mn, floatx4 Rw, const Pre4& p) {
-                    const int col = nb * 16 + (lane & 15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 4 * (lane >> 4) + r, grow = row0 + row;
-                        float act = 0.f;
-                        if (grow < a.N && col < A) {
-                            const float th = tanhf(Mn[r] / a.act_mean_scale);
-                            const float mean = a.act_mean_scale * th;
-                            const float pre = Rw[r] + a.act_raw_init_std;
-                            const float sd = softplusf(pre) + a.act_min_std;
-                            act = tanhf(mean + sd * p.v[r]);
-                            a.action[(tn + grow) * A + col] = act;
-                            mean_s[row * A + col] = mean;
-                            std_s[row * A + col] = sd;
-                            if (a.sv_act_stats) {
-                                float* st = a.sv_act_stats + (tn + grow) * 4 * A + col;
-                                st[0] = th;
-                                st[A] = sigmoidf(pre);
-                            }
+            tile_dual_head_elem<1>(
+                segs, a.b_a4, a.b_a4 + A, A, scratch,
+                [&](int row, int col) { return row0 + row < a.N ? a.eps_action[(tn + row0 + row) * A + col] : 0.f; },
+                [&](int row, int col, float Mn, float Rw, float eps) {
+                    const int grow = row0 + row;
+                    float act = 0.f;
+                    if (grow < a.N) {
+                        const float th = tanh_act(Mn / a.act_mean_scale);
+                        const float mean = a.act_mean_scale * th;
+                        const float pre = Rw + a.act_raw_init_std;
+                        const float sd = softplusf(pre) + a.act_min_std;
+                        act = tanh_act(mean + sd * eps);
+                        a.action[(tn + grow) * A + col] = act;
+                        mean_s[row * A + col] = mean;
+                        std_s[row * A + col] = sd;
+                        if (a.sv_act_stats) {
+                            float* st = a.sv_act_stats + (tn + grow) * 4 * A + col;
+                            st[0] = th;
+                            st[A] = sigmoidf(pre);
                         }
-                        af[acc_frag_off(nb, lane, r)] = act;
                     }
+                    af[frag_idx(row, col)] = act;
                 },
-                scratch);
+                t == 3 ? 0 : -1);
         }
         BD_STAMP(4);
         lds_barrier();
         BD_STAMP(5);
         // ---- entropy: n_samples draws per (row, action dim); thread = (row, sample lane) ----
         {
-            const int row = threadIdx.x & 15, sl = threadIdx.x >> 4;   // 16 sample lanes
+            const int row = tid & 15, sl = tid >> 4;   // 16 sample lanes
             const int grow = row0 + row;
             for (int j = 0; j < A; ++j) {
                 float lp = 0.f, dm = 0.f, ds = 0.f;
@@ -257,7 +245,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
             }
         }
         lds_barrier();
-        for (int i = threadIdx.x; i < 16 * A; i += blockDim.x) {
+        for (int i = tid; i < 16 * A; i += blockDim.x) {
             const int row = i / A, j = i - row * A, grow = row0 + row;
             float lp = 0.f, dm = 0.f, ds = 0.f;
             for (int w = 0; w < kWaves; ++w) {
@@ -272,10 +260,10 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
             }
         }
         lds_barrier();
-        if (threadIdx.x < 16 && row0 + threadIdx.x < a.N) {
+        if (tid < 16 && row0 + tid < a.N) {
             float s = 0.f;
-            for (int j = 0; j < A; ++j) s += lp_rj[threadIdx.x * A + j];
-            a.entropy[tn + row0 + threadIdx.x] = -s * inv_ns;
+            for (int j = 0; j < A; ++j) s += lp_rj[tid * A + j];
+            a.entropy[tn + row0 + tid] = -s * inv_ns;
         }
         BD_STAMP(6);
         // ---- embed ----
@@ -294,7 +282,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                 const int grow = row0 + 4 * (lane >> 4) + r;
                 const int off = acc_frag_off(nb, lane, r);
                 const float rr = sigmoidf(R[r]), zz = sigmoidf(Z[r]);
-                const float nn = tanhf(NI[r] + rr * NH[r]);
+                const float nn = tanh_act(NI[r] + rr * NH[r]);
                 const float hn = (1.f - zz) * nn + zz * h_cur[off];
                 const bool ok = grow < a.N && col < a.Be;
                 h_nxt[off] = ok ? hn : 0.f;
@@ -320,36 +308,23 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         BD_STAMP(12);
         {
             const Seg2 segs[1] = {{bufA, a.w_p2m, a.w_p2s, d.Kb_hd}};
-            tile_linear_dual_pre<1>(
-                segs, a.b_p2, a.b_p2 + a.S, a.S,
-                [&](int nb) {
-                    Pre4 p;
-                    const int col = nb * 16 + (lane & 15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int grow = row0 + 4 * (lane >> 4) + r;
-                        p.v[r] = (grow < a.N && col < a.S) ? a.eps_prior[(tn + grow) * a.S + col] : 0.f;
+            tile_dual_head_elem<1>(
+                segs, a.b_p2, a.b_p2 + a.S, a.S, scratch,
+                [&](int row, int col) { return row0 + row < a.N ? a.eps_prior[(tn + row0 + row) * a.S + col] : 0.f; },
+                [&](int row, int col, float Mn, float Rw, float eps) {
+                    const int grow = row0 + row;
+                    float st = 0.f;
+                    if (grow < a.N) {
+                        const size_t i = (tn + grow) * a.S + col;
+                        const float sd = softplusf(Rw) + a.min_std;
+                        st = Mn + sd * eps;
+                        if (a.prior_mean) a.prior_mean[i] = Mn;
+                        a.prior_std[i] = sd;
+                        a.feat[(tn + grow) * F + a.Be + col] = st;
                     }
-                    return p;
+                    sf[frag_idx(row, col)] = st;
                 },
-                [&](int nb, floatx4 Mn, floatx4 Rw, const Pre4& p) {
-                    const int col = nb * 16 + (lane & 15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int grow = row0 + 4 * (lane >> 4) + r;
-                        float st = 0.f;
-                        if (grow < a.N && col < a.S) {
-                            const size_t i = (tn + grow) * a.S + col;
-                            const float sd = softplusf(Rw[r]) + a.min_std;
-                            st = Mn[r] + sd * p.v[r];
-                            if (a.prior_mean) a.prior_mean[i] = Mn[r];
-                            a.prior_std[i] = sd;
-                            a.feat[(tn + grow) * F + a.Be + col] = st;
-                        }
-                        sf[acc_frag_off(nb, lane, r)] = st;
-                    }
-                },
-                scratch);
+                t == 3 ? 8 : -1);
         }
         BD_STAMP(13);
         lds_barrier();
@@ -362,7 +337,6 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
 __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ImgDims d(a.Be, a.S, a.A, a.Hd);
-    const int lane = threadIdx.x & 63;
     const int row0 = blockIdx.x * 16;
     const int F = a.Be + a.S, A = a.A;
     const int nh = d.Kb_h * kFragFloats, nhd = d.Kb_hd * kFragFloats, ns = d.Kb_s * kFragFloats,
@@ -390,22 +364,25 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
     const GruWT gw{a.wt_ir, a.wt_iz, a.wt_in, a.wt_hr, a.wt_hz, a.wt_hn};
     const size_t act_stride = (size_t)a.Hm * a.N * a.Hd;
 
-    auto dpre_epi = [&](float* dst, float* out, size_t tn, int width) {
-        return DpreEpi{dst, out, tn, width, a.N, row0, lane};
-    };
-    auto dpre_pre = [&](const float* saved, size_t tn, int width) { return DprePre{saved, tn, width, a.N, row0, lane}; };
-
     for (int t = a.Hm - 1; t >= 0; --t) {
         const size_t tn = (size_t)t * a.N;
+        const int tid = bd_tid();                   // opaque: nothing thread-dependent leaves this step (bd_tid)
+        const int lane = tid & 63;
+        auto dpre_epi = [&](float* dst, float* out, size_t tn_, int width) {
+            return DpreEpi{dst, out, tn_, width, a.N, row0, lane};
+        };
+        auto dpre_pre = [&](const float* saved, size_t tn_, int width) {
+            return DprePre{saved, tn_, width, a.N, row0, lane};
+        };
         // ---- 1: prior sample -> (mean, raw) ----
-        for (int i = threadIdx.x; i < 16 * d.Kb_s * 16; i += blockDim.x) {
+        for (int i = tid; i < 16 * d.Kb_s * 16; i += blockDim.x) {
             const int r = i / (d.Kb_s * 16), k = i - r * (d.Kb_s * 16);
             const int grow = row0 + r;
             float dm = 0.f, dr = 0.f;
             if (grow < a.N && k < a.S) {
                 const size_t idx = (tn + grow) * a.S + k;
                 dm = ds_plain[r * a.S + k] + a.dfeat[(tn + grow) * F + a.Be + k];
-                dr = dm * a.eps_prior[idx] * (-expm1f(-(a.prior_std[idx] - a.min_std)));
+                dr = dm * a.eps_prior[idx] * one_minus_exp_neg(a.prior_std[idx] - a.min_std);
             }
             dM[frag_idx(r, k)] = dm;
             dRaw[frag_idx(r, k)] = dr;
@@ -577,11 +554,15 @@ using namespace bd;
 int bd_debug_stamps(unsigned long long* out64) {
     return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
 }
+int bd_debug_dstamps(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dstamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
 #endif
 
 int bd_imagine_forward(const bd_imagine_fwd_args* a, void* stream) {
     BD_REQUIRE(a && a->N > 0 && a->Hm > 0 && a->Be > 0 && a->S > 0 && a->A > 0 && a->A <= kMaxA && a->Hd > 0 &&
                    a->n_samples > 0, "bd_imagine_forward: bad dims");
+    BD_REQUIRE(a->S <= kHeadMaxN && a->A <= kHeadMaxN, "bd_imagine_forward: state / action width above %d", kHeadMaxN);
     BD_REQUIRE(a->w_embed_s && a->w_embed_a && a->b_embed && a->w_ir && a->w_iz && a->w_in && a->w_hr && a->w_hz &&
                    a->w_hn && a->b_ih && a->b_hh && a->w_p1 && a->b_p1 && a->w_p2m && a->w_p2s && a->b_p2,
                "bd_imagine_forward: missing world-model weights");
@@ -611,8 +592,9 @@ int bd_imagine_backward(const bd_imagine_bwd_args* a, void* stream) {
                "bd_imagine_backward: missing forward tensors");
     BD_REQUIRE(a->d_actor_pre && a->d_actor_out, "bd_imagine_backward: missing outputs");
     const ImgDims d(a->Be, a->S, a->A, a->Hd);
+    // (the backward kernels have no element-wise Gaussian head: the split-K partials alone)
     const size_t lds = ((size_t)(6 * d.Kb_h + 3 * d.Kb_hd + 2 * d.Kb_s + 2 * d.Kb_a) * kFragFloats + 16 * a->S +
-                        kSplitScratchFloats) * sizeof(float);
+                        kSplitPartialFloats) * sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_imagine_backward: needs %zu B of LDS", lds);
     if (lds > 64 * 1024 && allow_big_lds(imagine_bwd_kernel)) return -1;
     hipLaunchKernelGGL(imagine_bwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kThreads) void observe_fwd_kernel(bd_observe_fwd_ar
                 const int grow = row0 + 4 * (lane >> 4) + r;
                 const int off = acc_frag_off(nb, lane, r);
                 const float rr = sigmoidf(R[r]), zz = sigmoidf(Z[r]);
-                const float nn = tanhf(NI[r] + rr * NH[r]);
+                const float nn = tanh_act(NI[r] + rr * NH[r]);
                 const float hn = (1.f - zz) * nn + zz * h_cur[off];
                 const bool ok = grow < a.B && col < a.Be;
                 h_nxt[off] = ok ? hn : 0.f;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kThreads) void observe_bwd_kernel(bd_observe_bwd_ar
                 dm = dst + (a.dpost_mean ? a.dpost_mean[idx] : 0.f);
                 const float dsd = dst * a.eps_post[idx] + (a.dpost_std ? a.dpost_std[idx] : 0.f);
                 // sigmoid(raw) from std = softplus(raw) + min_std:  1 - exp(-softplus(raw))
-                dr = dsd * (-expm1f(-(a.post_std[idx] - a.min_std)));
+                dr = dsd * one_minus_exp_neg(a.post_std[idx] - a.min_std);
                 a.d_q2_out[(tb + grow) * 2 * a.S + k] = dm;
                 a.d_q2_out[(tb + grow) * 2 * a.S + a.S + k] = dr;
             }

@@ -95,7 +95,6 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
                                                                 int tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ObsDimsC d(a.Be, a.S, a.A, a.Hd);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = blockIdx.x / C, c = blockIdx.x - tile * C;
     const int row0 = tile * 16;
     const int F = a.Be + a.S;
@@ -123,13 +122,15 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
     lds_barrier();
 
     const bool lead = (c == 0);     // the member that writes the redundantly computed outputs
-    const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(xf) + lane;
 
     for (int t = 0; t < a.T; ++t) {
         const size_t tb = (size_t)t * a.B;
+        const int tid = bd_tid();                   // opaque: nothing thread-dependent leaves this step (bd_tid)
+        const int lane = tid & 63, wave = tid >> 6;
+        const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(xf) + lane;
         BD_CSTAMP(0);
         // ---- A: masked state / action fragments (every member) ----
-        for (int i = threadIdx.x; i < 16 * d.Kb_s * 16; i += blockDim.x) {
+        for (int i = tid; i < 16 * d.Kb_s * 16; i += blockDim.x) {
             const int r = i / (d.Kb_s * 16), k = i - r * (d.Kb_s * 16);
             const int grow = row0 + r;
             float v = 0.f;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
             }
             sf[frag_idx(r, k)] = v;
         }
-        for (int i = threadIdx.x; i < 16 * d.Kb_a * 16; i += blockDim.x) {
+        for (int i = tid; i < 16 * d.Kb_a * 16; i += blockDim.x) {
             const int r = i / (d.Kb_a * 16), k = i - r * (d.Kb_a * 16);
             const int grow = row0 + r;
             af[frag_idx(r, k)] = (grow < a.B && k < a.A) ? a.actions[(tb + grow) * a.A + k] : 0.f;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
                 const int grow = row0 + 4 * (lane >> 4) + r;
                 const int off = acc_frag_off(my_nb, lane, r);
                 const float rr = sigmoidf(R[r]), zz = sigmoidf(Z[r]);
-                const float nn = tanhf(NI[r] + rr * NH[r]);
+                const float nn = tanh_act(NI[r] + rr * NH[r]);
                 const float hn = (grow < a.B && okc) ? (1.f - zz) * nn + zz * h_cur[off] : 0.f;
                 st_sc1(xb + off, hn);                        // write-through payload, fragment order
                 hn_keep[r] = hn;
@@ -289,39 +290,25 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
         // ---- E: posterior mean / std / sample (every member; split-K over waves) ----
         {
             const Seg2 segs[1] = {{qf, a.w_q2m, a.w_q2s, d.Kb_hd}};
-            tile_linear_dual_pre<1>(
-                segs, a.b_q2, a.b_q2 + a.S, a.S,
-                [&](int nb) {                 // posterior noise: fetched before the contraction
-                    Pre4 p;
-                    const int col = nb * 16 + (lane & 15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int grow = row0 + 4 * (lane >> 4) + r;
-                        p.v[r] = (grow < a.B && col < a.S) ? a.eps_post[(tb + grow) * a.S + col] : 0.f;
-                    }
-                    return p;
-                },
-                [&](int nb, floatx4 Mn, floatx4 Rw, const Pre4& p) {
-                    const int col = nb * 16 + (lane & 15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 4 * (lane >> 4) + r, grow = row0 + row;
-                        if (col >= a.S) continue;
-                        float st = 0.f;
-                        if (grow < a.B) {
-                            const size_t i = (tb + grow) * a.S + col;
-                            const float sd = softplusf(Rw[r]) + a.min_std;
-                            st = Mn[r] + sd * p.v[r];
-                            if (lead) {
-                                a.post_mean[i] = Mn[r];
-                                a.post_std[i] = sd;
-                                a.feat[(tb + grow) * F + a.Be + col] = st;
-                            }
+            tile_dual_head_elem<1>(
+                segs, a.b_q2, a.b_q2 + a.S, a.S, scratch,
+                // posterior noise: fetched before the contraction
+                [&](int row, int col) { return row0 + row < a.B ? a.eps_post[(tb + row0 + row) * a.S + col] : 0.f; },
+                [&](int row, int col, float Mn, float Rw, float eps) {
+                    const int grow = row0 + row;
+                    float st = 0.f;
+                    if (grow < a.B) {
+                        const size_t i = (tb + grow) * a.S + col;
+                        const float sd = softplusf(Rw) + a.min_std;
+                        st = Mn + sd * eps;
+                        if (lead) {
+                            a.post_mean[i] = Mn;
+                            a.post_std[i] = sd;
+                            a.feat[(tb + grow) * F + a.Be + col] = st;
                         }
-                        s_plain[row * a.S + col] = st;
                     }
-                },
-                scratch);
+                    s_plain[row * a.S + col] = st;
+                });
         }
         lds_barrier();
         BD_CSTAMP(10);
@@ -334,7 +321,6 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
                                                                 int tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ObsDimsC d(a.Be, a.S, a.A, a.Hd);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = blockIdx.x / C, c = blockIdx.x - tile * C;
     const int row0 = tile * 16;
     const int F = a.Be + a.S;
@@ -366,9 +352,11 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
 
     for (int t = a.T - 1; t >= 0; --t) {
         const size_t tb = (size_t)t * a.B;
+        const int tid = bd_tid();                   // opaque: nothing thread-dependent leaves this step (bd_tid)
+        const int lane = tid & 63, wave = tid >> 6;
         ++epoch;
         // ---- 1: through the sample / softplus into (mean, raw) (every member) ----
-        for (int i = threadIdx.x; i < 16 * d.Kb_s * 16; i += blockDim.x) {
+        for (int i = tid; i < 16 * d.Kb_s * 16; i += blockDim.x) {
             const int r = i / (d.Kb_s * 16), k = i - r * (d.Kb_s * 16);
             const int grow = row0 + r;
             float dm = 0.f, dr = 0.f;
@@ -377,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
                 const float dst = ds_plain[r * a.S + k] + a.dfeat[(tb + grow) * F + a.Be + k];
                 dm = dst + (a.dpost_mean ? a.dpost_mean[idx] : 0.f);
                 const float dsd = dst * a.eps_post[idx] + (a.dpost_std ? a.dpost_std[idx] : 0.f);
-                dr = dsd * (-expm1f(-(a.post_std[idx] - a.min_std)));
+                dr = dsd * one_minus_exp_neg(a.post_std[idx] - a.min_std);
                 if (lead) {
                     a.d_q2_out[(tb + grow) * 2 * a.S + k] = dm;
                     a.d_q2_out[(tb + grow) * 2 * a.S + a.S + k] = dr;
@@ -596,7 +584,7 @@ static size_t scratch_floats_fwd() {
 }
 static size_t scratch_floats_bwd() {
     const size_t gru = (size_t)kWaves * kLocalBlocks * 2 * 64 * 4;
-    return gru > (size_t)kSplitScratchFloats ? gru : (size_t)kSplitScratchFloats;
+    return gru > (size_t)kSplitPartialFloats ? gru : (size_t)kSplitPartialFloats;
 }
 
 }  // namespace bd
@@ -635,6 +623,7 @@ int bd_observe_forward_cluster(const bd_observe_fwd_args* a, float* ws, size_t w
                    a->w_hn && a->b_ih && a->b_hh && a->w_q1h && a->b_q1 && a->w_q2m && a->w_q2s && a->b_q2 &&
                    a->init_belief && a->init_state && a->actions && a->pre_emb && a->eps_post && a->feat &&
                    a->post_mean && a->post_std, "bd_observe_forward_cluster: missing pointers");
+    BD_REQUIRE(a->S <= kHeadMaxN, "bd_observe_forward_cluster: state width above %d", kHeadMaxN);
     const int C = pick_cluster(a->B, a->Be);
     BD_REQUIRE(C > 0, "bd_observe_forward_cluster: B=%d, Be=%d do not fit the cluster variant", a->B, a->Be);
     const int tiles = cdiv(a->B, 16);

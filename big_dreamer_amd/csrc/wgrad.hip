@@ -6,6 +6,7 @@
 // 64x64 output tile per workgroup, v_mfma_f32_32x32x2_f32 (exact fp32), operands staged through LDS.
 #include "bd_device.h"
 #include "bd_host.h"
+#include <stdlib.h>
 
 namespace bd {
 
@@ -146,6 +147,152 @@ __global__ __launch_bounds__(kThreads) void wgrad_grouped_kernel(const bd_wgrad_
     }
 }
 
+// ---- wide form of the grouped kernel (default) ----------------------------------------------------------------
+// The 64x64 tiles above re-read every operand row once per tile column/row of the output (4x for a 200x200 layer) and
+// pad 200 to 256 in both dimensions: 0.31 ms for the five GEMMs of an actor/critic pass whose MFMA floor is 0.09 ms.
+// Here a workgroup owns up to 13x13 16-blocks of the output -- a whole 200 x (200+bias) layer -- so each operand row is
+// read once per row split, and the 2x4 waves each keep up to 7x4 v_mfma_f32_16x16x4_f32 accumulators:
+// per 4-row slice a wave reads 7 + 4 operand dwords from LDS for 28 MFMAs.  Rows are staged 16 at a time through a
+// double-buffered LDS image with row stride 208 (== 16 mod 32: the 2 x 16-float rows a half-wave reads fall on
+// disjoint banks); the next stage's global loads fly under this stage's MFMAs; one barrier per stage.
+constexpr int kWB = 13;               // 16-blocks per workgroup tile edge
+constexpr int kWLd = 240;             // LDS row stride in floats: 14 blocks + pad, == 16 mod 32
+constexpr int kWRows = 16;            // rows per stage
+constexpr int kWStage = 2 * kWRows * kWLd;   // floats per stage: dpre rows | act rows
+constexpr int kWThreads = 512;        // 8 waves: 2 per SIMD, so LDS latency and the stage barrier hide under the other wave
+
+// WN x WK = 16-blocks per wave (the 2 x 4 waves cover up to 2WN x 4WK blocks).  The MFMA loop is branch-free: a wave
+// whose share is smaller multiplies zero-filled LDS columns (the workgroup runs at the pace of its fullest wave
+// anyway); only the stores are guarded.
+template <int WN, int WK>
+__device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* __restrict__ ws, float* wlds, int hb, int Kext,
+                                                int z, int n0, int k0, int nb_cnt, int kb_cnt) {
+    const int m_begin = z * d.rows_per;
+    const int m_end = min(d.M, m_begin + d.rows_per);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // 2 (n) x 4 (k) waves; wave = 2*wc + wr so that the two waves a SIMD hosts (w, w+4) carry 7x4+7x3, 6x4+6x3,
+    // 7x3+7x3, 6x3+6x3 blocks of a 13x13 tile (the fullest SIMD sets the pace: 49 of 42.25 on average)
+    const int wr = wave & 1, wc = wave >> 1;
+    const int hn = (nb_cnt + 1) >> 1;
+    const int my_nb0 = wr ? hn : 0, my_nb = wr ? nb_cnt - hn : hn;
+    const int kq = kb_cnt >> 2, krem = kb_cnt & 3;
+    const int my_kb0 = wc * kq + min(wc, krem), my_kb = kq + (wc < krem ? 1 : 0);
+
+    floatx4 acc[WN][WK];
+#pragma unroll
+    for (int i = 0; i < WN; ++i)
+#pragma unroll
+        for (int j = 0; j < WK; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // Staging by LDS-DMA (global_load_lds_dword: wave-uniform LDS base + lane*4, per-lane source address), so no
+    // staging registers compete with the accumulators.  Wave w carries rows 2w, 2w+1 of a stage; lanes cover the
+    // columns lane + 64*cc.  Columns beyond the tile / beyond N, K are never written and stay zero from the
+    // initial clear; the ones column (bias gradient) is written once; rows beyond the split's last row exist only in
+    // its final stage and are cleared there with ordinary LDS stores.
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    const int ncol = min(nb_cnt * 16, d.N - n0), kcol = min(kb_cnt * 16, d.K - k0);   // real columns of this tile
+    for (int i = threadIdx.x; i < 2 * kWStage; i += kWThreads) wlds[i] = 0.f;
+    __syncthreads();
+    if (hb && d.K >= k0 && d.K < k0 + kb_cnt * 16 && threadIdx.x < 2 * kWRows)
+        wlds[(threadIdx.x >> 4) * kWStage + kWRows * kWLd + (threadIdx.x & 15) * kWLd + (d.K - k0)] = 1.f;
+    auto issue = [&](float* buf, int m0) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int m = m0 + wave * 2 + rr;                      // wave-uniform
+            float* P = buf + (wave * 2 + rr) * kWLd;
+            float* A = P + kWRows * kWLd;
+            if (m < m_end) {
+                const float* prow = d.dpre + (size_t)m * d.ldp + n0;
+                const float* arow = (m < d.M1 ? d.act1 + (size_t)m * d.lda1 : d.act2 + (size_t)(m - d.M1) * d.lda2) + k0;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = lane + 64 * cc;
+                    if (c < ncol) __builtin_amdgcn_global_load_lds((glb_ptr_t)(prow + c), (lds_ptr_t)(P + 64 * cc), 4, 0, 0);
+                    if (c < kcol) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arow + c), (lds_ptr_t)(A + 64 * cc), 4, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = lane + 64 * cc;
+                    if (c < kWLd) {
+                        P[c] = 0.f;
+                        A[c] = 0.f;
+                    }
+                }
+            }
+        }
+    };
+    const int nst = cdiv(m_end - m_begin, kWRows);
+    __syncthreads();
+    issue(wlds, m_begin);
+    __builtin_amdgcn_s_waitcnt(0);     // vmcnt(0) lgkmcnt(0): the DMA has landed
+    __syncthreads();
+    const int lrow = lane >> 4, lcol = lane & 15;
+    for (int st = 0; st < nst; ++st) {
+        const float* buf = wlds + (st & 1) * kWStage;
+        // the other buffer was last read in stage st-1, which every wave has left (barrier below)
+        if (st + 1 < nst) issue(wlds + ((st + 1) & 1) * kWStage, m_begin + (st + 1) * kWRows);
+        const float* Pb = buf + lrow * kWLd + my_nb0 * 16 + lcol;
+        const float* Ab = buf + kWRows * kWLd + lrow * kWLd + my_kb0 * 16 + lcol;
+#pragma unroll
+        for (int sl = 0; sl < kWRows / 4; ++sl) {
+            float a[WN], b[WK];
+#pragma unroll
+            for (int i = 0; i < WN; ++i) a[i] = Pb[sl * 4 * kWLd + i * 16];
+#pragma unroll
+            for (int j = 0; j < WK; ++j) b[j] = Ab[sl * 4 * kWLd + j * 16];
+#pragma unroll
+            for (int i = 0; i < WN; ++i)
+#pragma unroll
+                for (int j = 0; j < WK; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    }
+    // lane holds D[n = 4*(lane>>4) + r][k = lane&15] of each 16x16 block
+    float* slab = ws + d.ws_off + (size_t)z * d.N * Kext;
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+        if (i < my_nb) {
+#pragma unroll
+            for (int j = 0; j < WK; ++j) {
+                if (j < my_kb) {
+                    const int k = k0 + (my_kb0 + j) * 16 + lcol;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int nn = n0 + (my_nb0 + i) * 16 + 4 * lrow + r;
+                        if (nn < d.N && k < Kext) slab[(size_t)nn * Kext + k] = acc[i][j][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kWThreads) void wgrad_wide_kernel(const bd_wgrad_desc* __restrict__ descs, int n,
+                                                         float* __restrict__ ws) {
+    extern __shared__ float wlds[];   // [2][ P: kWRows x kWLd | A: kWRows x kWLd ]
+    int g = 0;
+    while (g + 1 < n && (int)blockIdx.x >= descs[g + 1].block_begin) ++g;     // uniform scan, n is small
+    const bd_wgrad_desc d = descs[g];
+    const int hb = d.db != nullptr;
+    const int Kext = d.K + hb;
+    const int NB = cdiv(d.N, 16), KB = cdiv(Kext, 16);
+    const int nbw = cdiv(NB, d.tiles_n), kbw = cdiv(KB, d.tiles_k);           // <= kWB (bd_wgrad_plan)
+    int local = blockIdx.x - d.block_begin;
+    const int z = local / (d.tiles_n * d.tiles_k);
+    local -= z * d.tiles_n * d.tiles_k;
+    const int tn = local / d.tiles_k, tk = local - tn * d.tiles_k;
+    const int n0 = tn * nbw * 16, k0 = tk * kbw * 16;
+    const int nb_cnt = min(nbw, NB - tn * nbw), kb_cnt = min(kbw, KB - tk * kbw);
+    // narrow outputs (N <= 32: heads; K <= 32: 1..30 input features) keep one block per wave on that side
+    if (nb_cnt <= 2) wgrad_wide_body<1, 4>(d, ws, wlds, hb, Kext, z, n0, k0, nb_cnt, kb_cnt);
+    else if (kb_cnt <= 4) wgrad_wide_body<7, 1>(d, ws, wlds, hb, Kext, z, n0, k0, nb_cnt, kb_cnt);
+    else wgrad_wide_body<7, 4>(d, ws, wlds, hb, Kext, z, n0, k0, nb_cnt, kb_cnt);
+}
+
 __global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(const bd_wgrad_desc* __restrict__ descs, int n,
                                                                    const float* __restrict__ ws) {
     int g = 0;
@@ -162,6 +309,17 @@ __global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(const bd_wgra
     const int nn = e / Kext, k = e - nn * Kext;
     if (k < d.K) d.dW[(size_t)nn * d.ldw + k] = s;
     else d.db[nn] = s;
+}
+
+// BD_WGRAD_WIDE=0 selects the 64x64-tile grouped kernel; BD_WGRAD_ROWS = rows per workgroup of the wide form
+static bool wgrad_wide() {
+    static const char* e = getenv("BD_WGRAD_WIDE");
+    return !(e && e[0] == '0');
+}
+static int wgrad_rows() {
+    static const char* e = getenv("BD_WGRAD_ROWS");
+    const int r = e ? atoi(e) : 0;
+    return r >= kWRows ? cdiv(r, kWRows) * kWRows : 0;      // 0: fit one round (bd_wgrad_plan)
 }
 
 static void wgrad_plan(int M, int N, int K, int has_bias, int* splits, int* rows_per) {
@@ -184,6 +342,20 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
     BD_REQUIRE(descs && n > 0 && total_blocks && total_red_blocks && ws_floats, "bd_wgrad_plan: bad arguments");
     int blocks = 0, red = 0;
     size_t off = 0;
+    // wide form: one workgroup per CU (402 registers per lane), so the launch should be ONE round of the chip: the
+    // smallest row count per workgroup (multiple of the 16-row stage) for which all (tile, row split) pairs fit 256
+    int rows_wide = wgrad_rows();
+    if (wgrad_wide() && rows_wide == 0) {
+        auto wgs = [&](int R) {
+            long t = 0;
+            for (int i = 0; i < n; ++i)
+                t += (long)cdiv(cdiv(descs[i].N, 16), kWB) * cdiv(cdiv(descs[i].K + (descs[i].db != nullptr), 16), kWB) *
+                     cdiv(descs[i].M > 0 ? descs[i].M : 1, R);
+            return t;
+        };
+        rows_wide = 128;
+        while (wgs(rows_wide) > 256 && rows_wide < (1 << 20)) rows_wide += kWRows;
+    }
     for (int i = 0; i < n; ++i) {
         bd_wgrad_desc& d = descs[i];
         BD_REQUIRE(d.dpre && d.act1 && d.dW && d.M > 0 && d.N > 0 && d.K > 0 && d.M1 >= 0 && d.M1 <= d.M,
@@ -192,13 +364,21 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
         BD_REQUIRE(d.ldp >= d.N && d.lda1 >= d.K && d.ldw >= d.K && (d.M1 == d.M || d.lda2 >= d.K),
                    "bd_wgrad_plan: descriptor %d has a leading dimension that is too small", i);
         const int hb = d.db != nullptr;
-        d.tiles_n = cdiv(d.N, kWT);
-        d.tiles_k = cdiv(d.K + hb, kWT);
-        int s = d.M / 512;                      // ~512 rows (16 LDS stages) per workgroup
-        if (s < 1) s = 1;
-        if (s > 64) s = 64;
-        d.rows_per = cdiv(cdiv(d.M, s), kWM) * kWM;
-        d.splits = cdiv(d.M, d.rows_per);
+        if (wgrad_wide()) {
+            // tiles of <= 13 x 13 16-blocks, balanced; the row split is chosen below for the whole launch
+            d.tiles_n = cdiv(cdiv(d.N, 16), kWB);
+            d.tiles_k = cdiv(cdiv(d.K + hb, 16), kWB);
+            d.rows_per = rows_wide;
+            d.splits = cdiv(d.M, d.rows_per);
+        } else {
+            d.tiles_n = cdiv(d.N, kWT);
+            d.tiles_k = cdiv(d.K + hb, kWT);
+            int s = d.M / 512;                      // ~512 rows (16 LDS stages) per workgroup
+            if (s < 1) s = 1;
+            if (s > 64) s = 64;
+            d.rows_per = cdiv(cdiv(d.M, s), kWM) * kWM;
+            d.splits = cdiv(d.M, d.rows_per);
+        }
         d.block_begin = blocks;
         d.red_begin = red;
         d.ws_off = off;
@@ -217,7 +397,13 @@ int bd_wgrad_grouped(const bd_wgrad_desc* descs_dev, int n, int total_blocks, in
     using namespace bd;
     BD_REQUIRE(descs_dev && ws && n > 0 && n <= 4096 && total_blocks > 0 && total_red_blocks > 0,
                "bd_wgrad_grouped: bad arguments");
-    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(total_blocks), dim3(kThreads), 0, (hipStream_t)stream, descs_dev, n, ws);
+    if (wgrad_wide()) {
+        static_assert(kThreads == 256, "the 64x64-tile wgrad kernels are written for four waves");
+        hipLaunchKernelGGL(wgrad_wide_kernel, dim3(total_blocks), dim3(kWThreads), 2 * kWStage * sizeof(float), (hipStream_t)stream,
+                           descs_dev, n, ws);
+    } else {
+        hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(total_blocks), dim3(kThreads), 0, (hipStream_t)stream, descs_dev, n, ws);
+    }
     BD_CHECK_LAUNCH("bd_wgrad_grouped");
     hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3(total_red_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n,
                        ws);

@@ -30,6 +30,22 @@ for i, n in enumerate(names):
     dt = st[i + 1] - st[i]
     print(f"  {n:28s} {dt:8d} ticks  {100.0 * dt / tot:5.1f} %")
 
+fn3 = getattr(_cabi.lib, "bd_debug_dstamps", None)
+if fn3 is not None:
+    fn3.restype = ctypes.c_int
+    out3 = (ctypes.c_ulonglong * 64)()
+    assert fn3(out3) == 0
+    for base, title in ((0, "actor out + sample (split-K dual head)"), (8, "prior out + sample (split-K dual head)")):
+        st = np.array(out3[base:base + 6], dtype=np.int64)
+        names3 = ["issue operand (noise) load", "contraction + reduce -> LDS", "barrier", "wait vmcnt(0)", "element math + stores"]
+        print(f"{title}: {st[5] - st[0]} cycles   [drain older ops: {out3[base + 6] - st[0]}, operand load alone: "
+              f"{out3[base + 7] - out3[base + 6]}]")
+        for i, n in enumerate(names3):
+            print(f"  {n:40s} {st[i + 1] - st[i]:8d}")
+        si = np.array(out3[base + 16:base + 22], dtype=np.int64)
+        print("    inside the contraction: to first stamp", si[0] - st[1], "| loads+MFMAs", si[1] - si[0], "| partials->LDS", si[2] - si[1],
+              "| barrier", si[3] - si[2], "| reduce", si[4] - si[3], "| plain stores", si[5] - si[4], "| return", st[2] - si[5])
+
 # ---- cluster observe scan (forward), member 0 of tile 0, step 5 ----
 fn2 = getattr(_cabi.lib, "bd_debug_cstamps", None)
 if fn2 is not None:
