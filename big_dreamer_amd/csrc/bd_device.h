@@ -45,6 +45,12 @@ __device__ __forceinline__ int bd_tid() {
     asm volatile("" : "+v"(t));
     return t;
 }
+// Logical wave index: the hardware wave rotated by the workgroup index.  The column blocks of a 200-wide layer do not
+// divide evenly over the waves (13 blocks over 4 waves: one wave gets 4, three get 3), and hardware wave i of every
+// workgroup sits on SIMD i; rotating the roles makes the 2-3 co-resident workgroups of the dense-chain kernels
+// put their heavy wave on different SIMDs.  Every use of a wave index inside a kernel goes through this.
+static_assert((kWaves & (kWaves - 1)) == 0, "kWaves must be a power of two");
+__device__ __forceinline__ int bd_wave(int tid) { return ((tid >> 6) + (int)blockIdx.x) & (kWaves - 1); }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc emit s_waitcnt vmcnt(0), and
 // on CDNA4 vmcnt counts global STORES too: every phase of a persistent kernel would wait for its
@@ -103,7 +109,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // sum over the workgroup; result valid in thread 0.  `red` = kWaves doubles of LDS.
 __device__ __forceinline__ double block_sum_d(double v, double* red) {
     v = wave_sum_d(v);
-    const int lane = bd_tid() & 63, wave = bd_tid() >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // hardware wave: any block size
     __syncthreads();
     if (lane == 0) red[wave] = v;
     __syncthreads();
@@ -304,7 +310,7 @@ constexpr int kSplitScratchFloats = kSplitPartialFloats + kHeadPlainFloats;
 template <int RT, int NSEG, class Pre, class Epi>
 __device__ __forceinline__ void tile_linear_splitk(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
                                                    float* __restrict__ scratch, Pre&& pre, Epi&& epi) {
-    const int lane = bd_tid() & 63, wave = bd_tid() >> 6;
+    const int lane = bd_tid() & 63, wave = bd_wave(bd_tid());
     const int Nb = (N + 15) >> 4;
     const int P = Nb * RT;                      // <= kSplitPairs (checked by the caller)
     // the reducing waves fetch their bias and epilogue operands up front
@@ -372,7 +378,7 @@ __device__ __forceinline__ void tile_linear_splitk(const Seg (&seg)[NSEG], const
 template <int RT, int NSEG, class Pre, class Epi>
 __device__ __forceinline__ void tile_linear_pre(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Pre&& pre,
                                                 Epi&& epi, float* __restrict__ scratch = nullptr) {
-    const int wave = bd_tid() >> 6;
+    const int wave = bd_wave(bd_tid());
     const int Nb = (N + 15) >> 4;
     if (scratch != nullptr && Nb * RT <= kSplitPairs) {   // workgroup-uniform
         tile_linear_splitk<RT, NSEG>(seg, bias, N, scratch, pre, epi);
@@ -425,7 +431,7 @@ template <int NSEG, class Pre, class Epi>
 __device__ __forceinline__ void tile_linear_dual_pre(const Seg2 (&seg)[NSEG], const float* __restrict__ bias0,
                                                      const float* __restrict__ bias1, int N, Pre&& pre, Epi&& epi,
                                                      float* __restrict__ scratch = nullptr, int sb = -1) {
-    const int lane = bd_tid() & 63, wave = bd_tid() >> 6;
+    const int lane = bd_tid() & 63, wave = bd_wave(bd_tid());
     const int Nb = (N + 15) >> 4;
     if (scratch != nullptr && Nb <= kSplitPairs) {   // split-K over waves (see tile_linear_splitk); both W0, W1 given
         BD_DSTAMP(sb, 0);
@@ -623,7 +629,7 @@ struct GruFrag {
 template <class Epi>
 __device__ __forceinline__ void gru_tile(const float* __restrict__ X, const float* __restrict__ Hf, int Kb, int Be,
                                          const GruW& w, Epi&& epi) {
-    const int lane = bd_tid() & 63, wave = bd_tid() >> 6;
+    const int lane = bd_tid() & 63, wave = bd_wave(bd_tid());
     const int Nb = (Be + 15) >> 4;
     const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(X) + lane;
     const floatx4* __restrict__ H4 = reinterpret_cast<const floatx4*>(Hf) + lane;
@@ -677,7 +683,7 @@ template <class Pre, class Epi>
 __device__ __forceinline__ void gru_tile_bwd(const float* __restrict__ dR, const float* __restrict__ dZ,
                                              const float* __restrict__ dNI, const float* __restrict__ dNH, int Kb,
                                              int Be, const GruWT& w, Pre&& pre, Epi&& epi) {
-    const int lane = bd_tid() & 63, wave = bd_tid() >> 6;
+    const int lane = bd_tid() & 63, wave = bd_wave(bd_tid());
     const int Nb = (Be + 15) >> 4;
     const floatx4* __restrict__ R4 = reinterpret_cast<const floatx4*>(dR) + lane;
     const floatx4* __restrict__ Z4 = reinterpret_cast<const floatx4*>(dZ) + lane;

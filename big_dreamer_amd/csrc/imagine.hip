@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
     for (int t = 0; t < a.Hm; ++t) {
         const size_t tn = (size_t)t * a.N;
         const int tid = bd_tid();                   // opaque: nothing thread-dependent leaves this step (bd_tid)
-        const int lane = tid & 63, wave = tid >> 6;
+        const int lane = tid & 63, wave = bd_wave(tid);
         // hidden layer epilogue: ELU -> LDS fragment (+ optional save)
         auto hidden_epi = [&](float* dst, float* save, size_t tn_, int width) {
             return HiddenEpi{dst, save, tn_, width, a.N, row0, lane};

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
     for (int t = 0; t < a.T; ++t) {
         const size_t tb = (size_t)t * a.B;
         const int tid = bd_tid();                   // opaque: nothing thread-dependent leaves this step (bd_tid)
-        const int lane = tid & 63, wave = tid >> 6;
+        const int lane = tid & 63, wave = bd_wave(tid);
         const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(xf) + lane;
         BD_CSTAMP(0);
         // ---- A: masked state / action fragments (every member) ----
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
     for (int t = a.T - 1; t >= 0; --t) {
         const size_t tb = (size_t)t * a.B;
         const int tid = bd_tid();                   // opaque: nothing thread-dependent leaves this step (bd_tid)
-        const int lane = tid & 63, wave = tid >> 6;
+        const int lane = tid & 63, wave = bd_wave(tid);
         ++epoch;
         // ---- 1: through the sample / softplus into (mean, raw) (every member) ----
         for (int i = tid; i < 16 * d.Kb_s * 16; i += blockDim.x) {

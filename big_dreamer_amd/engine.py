@@ -107,7 +107,7 @@ class WgradBatch:
 
 class DreamerEngine:
     def __init__(self, dims: Dims, hp: Optional[dict] = None, device="cuda", params: Optional[dict] = None,
-                 world_size: int = 1, process_group=None):
+                 world_size: int = 1, process_group=None, phase_groups: Optional[dict] = None):
         self.d = dims
         self.pixel = bool(dims.pixel)   # conv encoder / decoder through MIOpen (torch), everything else HIP kernels
         self.hp = dict(DEFAULT_HP)
@@ -118,7 +118,7 @@ class DreamerEngine:
         self.world_size = world_size
         self.pg = process_group
         self.dp = DataParallel(world_size, torch.distributed.get_rank(process_group) if world_size > 1 else 0,
-                               process_group)
+                               process_group, phase_groups)
         d = dims
         shapes = param_shapes(d)
         self.groups = {
@@ -345,13 +345,13 @@ class DreamerEngine:
             batch.add(dpres[l], sizes[l + 1], act, lda, M, sizes[l + 1], sizes[l],
                       self.G(mod, f"model.{2 * l}.weight"), sizes[l], self.G(mod, f"model.{2 * l}.bias"))
 
-    def _allreduce(self, t: torch.Tensor) -> None:
-        self.dp.allreduce_sum_(t)
+    def _allreduce(self, t: torch.Tensor, key: Optional[str] = None) -> None:
+        self.dp.allreduce_sum_(t, key)
 
     def optimizer_step(self, group: str, slot: int, lr: float, red_ws: Optional[torch.Tensor] = None) -> None:
         g = self.groups[group]
         red_ws = self.red_ws if red_ws is None else red_ws
-        self._allreduce(g.grad)       # grads already carry 1/global-count: SUM over ranks = global-mean gradient
+        self._allreduce(g.grad, group)       # grads already carry 1/global-count: SUM over ranks = global-mean gradient
         g.step += 1
         hp = self.hp
         cabi.check(lib.bd_sumsq(ptr(g.grad), g.numel, ptr(self.scalars), slot, ptr(red_ws), cabi.stream()))
@@ -628,7 +628,7 @@ class DreamerEngine:
         cabi.check(lib.bd_kl_forward(ptr(qm), ptr(qs), ptr(pm), ptr(ps), N, d.S, hp["free_nats"], sum_form, sc, SLOT_KL, ws, st))
         if W > 1 and not sum_form:                          # the free-nats clamp acts on the GLOBAL mean
             self._kl_local = self.scalars[SLOT_KL:SLOT_KL + 1].clone()
-            self._allreduce(self.scalars[SLOT_KL:SLOT_KL + 1])
+            self._allreduce(self.scalars[SLOT_KL:SLOT_KL + 1], "model")
         dqm, dqs = self.buf("dqm", N, d.S), self.buf("dqs", N, d.S)
         dpm, dps = self.buf("dpm", N, d.S), self.buf("dps", N, d.S)
         kl_inv = 1.0 / (N * d.S * W) if not sum_form else 1.0 / (N * W)

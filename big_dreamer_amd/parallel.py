@@ -20,9 +20,19 @@ import torch
 
 
 class DataParallel:
-    def __init__(self, world_size: int = 1, rank: int = 0, process_group=None):
+    def __init__(self, world_size: int = 1, rank: int = 0, process_group=None, groups: Optional[dict] = None):
+        """`groups` may map "model" / "actor" / "critic" to separate process groups.  The engine's cross-step pipeline
+        issues the three gradient all-reduces from three HIP streams; on ONE communicator they would execute in issue
+        order (model k, actor k, critic k, model k+1, ...), so the world model's all-reduce of step k+1 would wait
+        for the low-priority critic update of step k.  One RCCL communicator per optimiser removes that coupling."""
         assert world_size >= 1 and 0 <= rank < world_size
         self.world_size, self.rank, self.pg = world_size, rank, process_group
+        self.groups = dict(groups or {})
+
+    @staticmethod
+    def make_phase_groups(backend: Optional[str] = None) -> dict:
+        """Three process groups over all ranks (collective: every rank calls it, once)."""
+        return {k: torch.distributed.new_group(backend=backend) for k in ("model", "actor", "critic")}
 
     # ---- scaling --------------------------------------------------------------------------------------
     def mean_grad_scale(self, local_count: int) -> float:
@@ -30,15 +40,16 @@ class DataParallel:
         return 1.0 / (local_count * self.world_size)
 
     # ---- collectives -----------------------------------------------------------------------------------
-    def allreduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+    def allreduce_sum_(self, t: torch.Tensor, key: Optional[str] = None) -> torch.Tensor:
         if self.world_size > 1:
-            if t.is_cuda and torch.distributed.get_backend(self.pg) == "gloo":
+            pg = self.groups.get(key, self.pg)
+            if t.is_cuda and torch.distributed.get_backend(pg) == "gloo":
                 # test transport only (several ranks sharing one GPU): stage through the host
                 h = t.detach().cpu()
-                torch.distributed.all_reduce(h, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                torch.distributed.all_reduce(h, op=torch.distributed.ReduceOp.SUM, group=pg)
                 t.copy_(h)
             else:
-                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=pg)
         return t
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:

@@ -26,7 +26,8 @@ def main():
     batch = {k: torch.as_tensor(v) for k, v in synth.make_batch(d, 4).items()}
     noise = {k: torch.as_tensor(v) for k, v in synth.make_noise(d, 4).items()}
     hp = dict(planning_horizon=d.H, free_nats=free_nats)
-    dp = DataParallel(world, rank)
+    # one process group per optimiser, as bench.py builds them for the pipelined engine (here: gloo)
+    dp = DataParallel(world, rank, groups=DataParallel.make_phase_groups("gloo"))
 
     # ---- this rank's shard ----
     lb = dp.shard_batch(batch)
@@ -43,7 +44,7 @@ def main():
     kl_el_lhs = O.kl_normal(qm.detach(), qs.detach(), pm, ps)
     kl_el_rhs = O.kl_normal(qm, qs, pm.detach(), ps.detach())
     kl_sum = kl_el_rhs.detach().sum().reshape(1).clone()
-    dp.allreduce_sum_(kl_sum)                                     # ONE float before the clamp decision
+    dp.allreduce_sum_(kl_sum, "model")                                     # ONE float before the clamp decision
     kl_mean = kl_sum / (d.N * d.S)
     gate = 1.0 if float(kl_mean) > free_nats else (0.5 if float(kl_mean) == free_nats else 0.0)
     kl_scale = gate / (d.N * d.S)
@@ -51,7 +52,7 @@ def main():
         od.hp["kl_balance"] * kl_el_lhs.sum() + (1 - od.hp["kl_balance"]) * kl_el_rhs.sum())
     g = torch.autograd.grad(loss, od.model_params, allow_unused=True)
     flat = torch.cat([(torch.zeros_like(p) if gi is None else gi).reshape(-1) for gi, p in zip(g, od.model_params)])
-    dp.allreduce_sum_(flat)                                       # SUM of 1/global-count-scaled grads = global mean grad
+    dp.allreduce_sum_(flat, "model")                                       # SUM of 1/global-count-scaled grads = global mean grad
 
     # ---- reference: the whole batch in one process ----
     if rank == 0:
