@@ -384,7 +384,11 @@ __device__ __forceinline__ void tile_linear_pre(const Seg (&seg)[NSEG], const fl
         tile_linear_splitk<RT, NSEG>(seg, bias, N, scratch, pre, epi);
         return;
     }
-    constexpr int D = 2;
+#ifndef BD_PIPE_D
+#define BD_PIPE_D 2
+#endif
+    constexpr int D = BD_PIPE_D;      // K blocks per register set of the software pipeline (two sets); measured on
+                                      // MI355X after the kernels became spill-free: D = 3 / 4 are 4-6 % slower than 2
     for (int nb0 = wave; nb0 < Nb; nb0 += 2 * kWaves) {
         if (nb0 + kWaves < Nb) linear_blocks<NSEG, RT, 2, D>(seg, bias, N, nb0, pre, epi);
         else linear_blocks<NSEG, RT, 1, D>(seg, bias, N, nb0, pre, epi);
