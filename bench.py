@@ -127,10 +127,9 @@ def main():
     d = synth.CONFIG3 if args.pixel else synth.CONFIG2
     np.random.seed(rank)
     torch.manual_seed(rank)
-    # one RCCL communicator per optimiser: the pipeline's three gradient all-reduces come from three streams
-    from big_dreamer_amd.parallel import DataParallel
-    phase_groups = DataParallel.make_phase_groups("nccl") if world > 1 else None
-    eng = DreamerEngine(d, None, dev, params=synth.make_params(d, 0), world_size=world, phase_groups=phase_groups)
+    # (one communicator: the engine issues the actor / critic all-reduces one host step late so that they never sit in
+    # front of the next step's world-model all-reduce -- engine._optimizer_step_or_defer)
+    eng = DreamerEngine(d, None, dev, params=synth.make_params(d, 0), world_size=world)
     rep = synth.make_replay(d if not args.pixel else synth.Dims(A=d.A, O=3), rows=5000, seed=0)
     buf = ExperienceReplay(5000, d.A, 5, args.pixel, d.O, dev)
     if args.pixel:      # uniform uint8 frames

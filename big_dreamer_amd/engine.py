@@ -164,6 +164,10 @@ class DreamerEngine:
         self._ev_bh_wm_free: Optional[torch.cuda.Event] = None
         self._ev_bh_done: List[Optional[torch.cuda.Event]] = [None, None]
         self._ev_cr_done: List[Optional[torch.cuda.Event]] = [None, None]
+        # data-parallel: actor / critic optimiser steps (their all-reduces) are issued one host step late, see
+        # _optimizer_step_or_defer; BD_DEFER_OPT=1 forces the same order on one GPU (tests)
+        self.defer_opt = world_size > 1 or os.environ.get("BD_DEFER_OPT", "0") == "1"
+        self._pending_opt: List[tuple] = []
         self._parity = 0
         self._wgrad_ws_bh = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.red_ws_bh = torch.zeros(int(lib.bd_reduce_ws_floats()), dtype=torch.float32, device=self.dev)
@@ -541,9 +545,29 @@ class DreamerEngine:
             shapes.update(action=(Hm, N, d.A), entropy=(Hm, d.n_entropy, N, d.A), img_prior=(Hm, N, d.S))
         return {k: self.buf("noise_" + k, *s).normal_() for k, s in shapes.items()}
 
+    def _optimizer_step_or_defer(self, span: str, group: str, slot: int, lr: float, red_ws: torch.Tensor) -> None:
+        """Actor / critic optimiser step of the behaviour phase.  Data-parallel + pipelined: queued and issued by the NEXT
+        train_step right after its dynamics phase (or by join()).  All ranks share ONE communicator, whose collectives
+        execute in issue order; issued here, actor k's all-reduce (ready at the end of behaviour learning k) would sit in
+        front of the KL / world-model all-reduces of step k+1 and stall dynamics learning k+1 half-way.  Deferred, the
+        order per host step is kl, model (k+1), actor, critic (k): each is ready by the time its turn comes."""
+        if self.pipeline and self.defer_opt:
+            self._pending_opt.append((span, group, slot, lr, red_ws, torch.cuda.current_stream()))
+            return
+        with self.span(span):
+            self.optimizer_step(group, slot, lr, red_ws)
+
+    def _flush_pending_opt(self) -> None:
+        pend, self._pending_opt = self._pending_opt, []
+        for span, group, slot, lr, red_ws, stream in pend:
+            with torch.cuda.stream(stream):
+                with self.span(span):
+                    self.optimizer_step(group, slot, lr, red_ws)
+
     def join(self) -> None:
         """Order everything the pipeline streams have been given before later work on the caller's stream."""
         if self.pipeline:
+            self._flush_pending_opt()
             cur = torch.cuda.current_stream()
             cur.wait_stream(self._s_wm)
             cur.wait_stream(self._s_bh)
@@ -584,6 +608,7 @@ class DreamerEngine:
             feat = self._dynamics_phase(batch, nz, f"p{par}_")
             ev_wm_done = torch.cuda.Event()
             ev_wm_done.record(s_wm)
+        self._flush_pending_opt()                   # actor / critic updates of the previous step (data-parallel runs)
         with torch.cuda.stream(s_bh):
             s_bh.wait_event(ev_wm_done)
             nz = noise if noise is not None else self.make_noise(B, "bh")
@@ -813,8 +838,7 @@ class DreamerEngine:
                Ga(f"model.{2 * DENSE_LAYERS}.weight"), d.Hd, Ga(f"model.{2 * DENSE_LAYERS}.bias"))
         with self.span("wgrad_actor"):
             wa.run()
-        with self.span("opt_actor"):
-            self.optimizer_step("actor", SLOT_GN_ACTOR, hp["actor_learning_rate"], red_ws)
+        self._optimizer_step_or_defer("opt_actor", "actor", SLOT_GN_ACTOR, hp["actor_learning_rate"], red_ws)
 
         if par is not None:
             pass
@@ -839,8 +863,7 @@ class DreamerEngine:
         self._dense_wgrads(wc, "critic", Mi, c_dpre, ifeat, F, c_acts, [F] + [d.Hd] * DENSE_LAYERS + [1])
         with self.span("wgrad_critic"):
             wc.run()
-        with self.span("opt_critic"):
-            self.optimizer_step("critic", SLOT_GN_CRITIC, hp["value_learning_rate"], red_ws)
+        self._optimizer_step_or_defer("opt_critic", "critic", SLOT_GN_CRITIC, hp["value_learning_rate"], red_ws)
 
     def logs(self) -> Dict[str, float]:
         """One D2H copy of the scalar board -> the reference's log dict (src/dreamer.py:293-296,359-360,383).

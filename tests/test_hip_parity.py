@@ -155,9 +155,10 @@ def test_pipelined_schedule_is_bit_identical_to_serial(name):
     d, seed, hp, _full = CASES[name]
     P = synth.make_params(d, seed)
     engs = []
-    for pipe in (True, False):
+    for pipe, defer in ((True, False), (False, False), (True, True)):
         eng = DreamerEngine(d, hp, "cuda", params=P)
         eng.pipeline = pipe
+        eng.defer_opt = defer        # the data-parallel order of the optimiser steps (engine._optimizer_step_or_defer)
         engs.append(eng)
     steps = 4
     batches = [_dev(synth.make_batch(d, seed + 10 * i)) for i in range(steps)]
@@ -172,13 +173,14 @@ def test_pipelined_schedule_is_bit_identical_to_serial(name):
         logs.append(eng.logs())
         torch.cuda.synchronize()
         eng.cluster_status(d.B)
-    a, b = engs
-    for grp in ("model", "actor", "critic", "critic_target"):
-        ga, gb = a.groups[grp], b.groups[grp]
-        assert torch.equal(ga.flat, gb.flat), grp
-        if ga.grad is not None:
-            assert torch.equal(ga.grad, gb.grad) and torch.equal(ga.m, gb.m) and torch.equal(ga.v, gb.v), grp
-    assert logs[0] == logs[1]
+    b = engs[1]
+    for i, a in enumerate(engs):
+        for grp in ("model", "actor", "critic", "critic_target"):
+            ga, gb = a.groups[grp], b.groups[grp]
+            assert torch.equal(ga.flat, gb.flat), (i, grp)
+            if ga.grad is not None:
+                assert torch.equal(ga.grad, gb.grad) and torch.equal(ga.m, gb.m) and torch.equal(ga.v, gb.v), (i, grp)
+        assert logs[i] == logs[1], i
     assert np.isfinite(list(logs[0].values())).all()
 
 
