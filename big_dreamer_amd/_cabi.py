@@ -97,6 +97,15 @@ class ImagineBwdArgs(C.Structure):
         ("dentropy", F32)] + _ptr_fields(["d_actor_pre", "d_actor_out"]))
 
 
+class ConvArgs(C.Structure):
+    _fields_ = [("in_", P), ("out", P), ("w", P), ("bias", P),
+                ("imgs", I32), ("gh", I32), ("gw", I32), ("N", I32), ("K", I32),
+                ("nseg", I32), ("seglen", I32), ("C", I32), ("IH", I32), ("IW", I32), ("sy", I32), ("y0", I32),
+                ("ss", I32), ("sx", I32), ("x0", I32), ("mask", I32), ("cshift", I32), ("vec4", I32),
+                ("OH", I32), ("OW", I32), ("osy", I32), ("oy0", I32), ("osx", I32), ("ox0", I32), ("ldo", I32),
+                ("act", I32)]
+
+
 # every symbol include/bigdreamer_hip.h declares, with its signature
 _SIGS = {
     "bd_last_error": (C.c_char_p, []),
@@ -132,6 +141,10 @@ _SIGS = {
     "bd_replay_gather": (I32, [P, P, I32, I32, P, P]),
     "bd_replay_gather_pixels": (I32, [P, P, I32, I32, I32, P, P, P]),
     "bd_reduce_ws_floats": (C.c_size_t, []),
+    "bd_conv_gemm": (I32, [C.POINTER(ConvArgs), P]),
+    "bd_conv_pack_class": (I32, [P, P, I32, I32, I32, I32, I32, I32, I32, P]),
+    "bd_elu_backward": (I32, [P, P, C.c_size_t, P]),
+    "bd_image_layout": (I32, [P, P, I32, I32, I32, I32, P]),
 }
 
 for _name, (_res, _args) in _SIGS.items():

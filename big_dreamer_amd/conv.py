@@ -1,0 +1,107 @@
+"""Host side of the hand-written conv stacks (csrc/conv.hip): geometry of the two gather patterns and the packed
+weight copies.  Activations are NHWC fp32; Conv2d weights are stored (co, ky, kx, ci), ConvTranspose2d weights
+(ci, ky, kx, co) -- see conv.hip.  All convolutions of the reference's stacks are stride 2, no padding
+(src/models.py:319-362, 527-564)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Tuple
+
+import torch
+
+from . import _cabi as cabi
+
+lib = cabi.lib
+ptr = cabi.ptr
+
+
+def _log2(c: int) -> int:
+    return c.bit_length() - 1 if c & (c - 1) == 0 else 0
+
+
+def conv_out(size: int, k: int) -> int:
+    """Output size of a stride-2 VALID convolution."""
+    return (size - k) // 2 + 1
+
+
+def convT_out(size: int, k: int) -> int:
+    return (size - 1) * 2 + k
+
+
+def taps(k: int, parity: int) -> int:
+    """Kernel taps ky = parity + 2a < k of one output parity class of a stride-2 transposed convolution."""
+    return (k - parity + 1) // 2
+
+
+def pattern_f(inp: torch.Tensor, out: torch.Tensor, w_packed: torch.Tensor, bias, imgs: int, IH: int, IW: int, Cin: int,
+              k: int, N: int, act: int) -> None:
+    """out (imgs, OH, OW, N) = conv_stride2_valid(inp (imgs, IH, IW, Cin)) with packed W[N][(ky, kx, ci)] (+bias, act).
+    Also the dgrad of a transposed convolution (inp = gradient of its output)."""
+    OH, OW = conv_out(IH, k), conv_out(IW, k)
+    a = cabi.ConvArgs()
+    a.in_, a.out, a.w, a.bias = ptr(inp), ptr(out), ptr(w_packed), ptr(bias)
+    a.imgs, a.gh, a.gw, a.N, a.K = imgs, OH, OW, N, k * k * Cin
+    a.nseg, a.seglen, a.C, a.IH, a.IW = k, k * Cin, Cin, IH, IW
+    a.sy, a.y0, a.ss, a.sx, a.x0, a.mask = 2, 0, 1, 2, 0, 0
+    a.vec4 = int(Cin % 4 == 0)
+    a.cshift = _log2(Cin)
+    a.OH, a.OW, a.osy, a.oy0, a.osx, a.ox0, a.ldo = OH, OW, 1, 0, 1, 0, N
+    a.act = act
+    cabi.check(lib.bd_conv_gemm(C.byref(a), cabi.stream()))
+
+
+def pattern_t(inp: torch.Tensor, out: torch.Tensor, w_classes: List[torch.Tensor], bias, imgs: int, IH: int, IW: int,
+              Cin: int, k: int, N: int, OH: int, OW: int, act: int) -> None:
+    """out (imgs, OH, OW, N) = convT_stride2(inp (imgs, IH, IW, Cin)) restricted to the rows/cols < OH, OW, from the four
+    parity-class weight packs (class_packs).  Also the dgrad of a stride-2 convolution (inp = gradient of its output,
+    OH/OW = the convolution's input size: pixels no window covers get a zero gradient)."""
+    assert Cin % 4 == 0 and Cin & (Cin - 1) == 0, "T pattern: channel count must be a power of two >= 4"
+    for py in range(2):
+        for px in range(2):
+            Ta, Tb = taps(k, py), taps(k, px)
+            gh, gw = (OH - py + 1) // 2, (OW - px + 1) // 2
+            if gh <= 0 or gw <= 0:
+                continue
+            a = cabi.ConvArgs()
+            a.in_, a.out, a.w, a.bias = ptr(inp), ptr(out), ptr(w_classes[2 * py + px]), ptr(bias)
+            a.imgs, a.gh, a.gw, a.N, a.K = imgs, gh, gw, N, Ta * Tb * Cin
+            a.nseg, a.seglen, a.C, a.IH, a.IW = Ta, Tb * Cin, Cin, IH, IW
+            a.sy, a.y0, a.ss, a.sx, a.x0, a.mask = 1, 0, -1, 1, -(Tb - 1), 1
+            a.vec4, a.cshift = 1, _log2(Cin)
+            a.OH, a.OW, a.osy, a.oy0, a.osx, a.ox0, a.ldo = OH, OW, 2, py, 2, px, N
+            a.act = act
+            cabi.check(lib.bd_conv_gemm(C.byref(a), cabi.stream()))
+
+
+def class_pack_floats(Couter: int, Cinner: int, k: int) -> List[int]:
+    return [cabi.packed_floats(Cinner, taps(k, py) * taps(k, px) * Couter) for py in range(2) for px in range(2)]
+
+
+def pack_classes(stored: torch.Tensor, dsts: List[torch.Tensor], Couter: int, Cinner: int, k: int) -> None:
+    """stored: (Couter, k, k, Cinner) contiguous -> the four parity-class packs of the T pattern."""
+    for py in range(2):
+        for px in range(2):
+            cabi.check(lib.bd_conv_pack_class(ptr(stored), ptr(dsts[2 * py + px]), Couter, Cinner, k, py, px, taps(k, py),
+                                              taps(k, px), cabi.stream()))
+
+
+def pack_matrix(src2d: torch.Tensor, dst: torch.Tensor, N: int, K: int, transpose: bool = False) -> None:
+    """bd_pack_weights on one (N, K) row-major matrix view (stride(0) = leading dimension)."""
+    d = (cabi.PackDesc * 1)(cabi.PackDesc(src2d.data_ptr(), dst.data_ptr(), src2d.stride(0), N, K, int(transpose)))
+    raw = torch.frombuffer(bytearray(bytes(d)), dtype=torch.uint8).to(src2d.device)
+    cabi.check(lib.bd_pack_weights(raw.data_ptr(), 1, cabi.stream()))
+    torch.cuda.current_stream().synchronize()      # `raw` must outlive the launch (test / setup helper only)
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    imgs, Cc, H, W = x.shape
+    out = torch.empty(imgs, H, W, Cc, dtype=torch.float32, device=x.device)
+    cabi.check(lib.bd_image_layout(ptr(x.contiguous()), ptr(out), imgs, Cc, H * W, 1, cabi.stream()))
+    return out
+
+
+def to_nchw(x: torch.Tensor) -> torch.Tensor:
+    imgs, H, W, Cc = x.shape
+    out = torch.empty(imgs, Cc, H, W, dtype=torch.float32, device=x.device)
+    cabi.check(lib.bd_image_layout(ptr(x.contiguous()), ptr(out), imgs, Cc, H * W, 0, cabi.stream()))
+    return out

@@ -1,0 +1,283 @@
+// conv.hip -- the 64x64 conv stacks of the pixel configurations (CnnImageEncoder src/models.py:527-564,
+// ObservationModel src/models.py:319-362) as gather-GEMMs on the fp32 MFMA tile machinery of this library.
+//
+// Activations are NHWC fp32 images.  Every stride-2 layer of the two stacks, forward and backward, is one of two
+// gather patterns in front of the same contraction out[m][n] = sum_k A(m, k) W[n][k] (+ bias, ELU):
+//   F  rows = output pixels of a stride-2 VALID convolution; A(m, .) = the k x k x C window, read as k segments of
+//      k*C contiguous floats (NHWC makes (kx, ci) contiguous).  Conv2d forward; ConvTranspose2d dgrad.
+//   T  rows = one parity class (oy%2, ox%2) of the output pixels of a stride-2 transposed convolution (sub-pixel
+//      decomposition: each class is a dense stride-1 convolution with the taps ky = py + 2a, kx = px + 2b);
+//      A(m, .) = Ta segments of Tb*C contiguous floats, masked at the image border.  ConvTranspose2d forward; Conv2d
+//      dgrad.  The class results are scattered to the stride-2 positions of the output image.
+// Weights live in the parameter buffer as (co, ky, kx, ci) for Conv2d and (ci, ky, kx, co) for ConvTranspose2d, so the
+// F contractions and both weight-gradient GEMMs (wgrad.hip, gathered `act` operand) use them as plain [N][K] matrices
+// and only the T classes need a re-pack (conv_pack_class_kernel).
+//
+// A workgroup (8 waves) owns 16*RT rows: the gathered A tile goes to LDS in MFMA fragment order once, then the
+// RT * Nb (row tile, column block) units are dealt out contiguously over the waves and each run of units on one column
+// block streams its packed weight fragments from L2 once (software-pipelined K loop, v_mfma_f32_16x16x4_f32).
+#include "bd_device.h"
+#include "bd_host.h"
+#include <stdlib.h>
+
+namespace bd {
+
+template <int RTC>
+struct ConvFrag {
+    floatx4 a[RTC];
+    floatx4 b;
+};
+
+// One segment: column block nb, row tiles rt0 .. rt0+RTC-1 of the LDS tile X[rt][Kb] (fragment order).
+template <int RTC, class Epi>
+__device__ __forceinline__ void conv_segment(const float* __restrict__ X, int Kb, const float* __restrict__ Wp,
+                                             const float* __restrict__ bias, int N, int nb, int rt0, Epi&& epi) {
+    const int lane = bd_tid() & 63;
+    const int col = nb * 16 + (lane & 15);
+    const float b = (bias != nullptr && col < N) ? bias[col] : 0.f;
+    floatx4 acc[RTC], acc2[RTC];      // two chains per row tile: a lone dependent chain pays 40 cycles per 32-cycle MFMA
+#pragma unroll
+    for (int r = 0; r < RTC; ++r) {
+        acc[r] = floatx4{b, b, b, b};
+        acc2[r] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(X) + lane;
+    const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(Wp) + lane + (size_t)nb * Kb * 64;
+    pipelined_k<2>(
+        Kb,
+        [&](int kb) {
+            ConvFrag<RTC> f;
+            f.b = W4[(size_t)kb * 64];
+#pragma unroll
+            for (int r = 0; r < RTC; ++r) f.a[r] = X4[((rt0 + r) * Kb + kb) * 64];
+            return f;
+        },
+        [&](const ConvFrag<RTC>& f) {
+#pragma unroll
+            for (int r = 0; r < RTC; ++r) {
+                acc[r] = mfma16(f.a[r][0], f.b[0], acc[r]);
+                acc2[r] = mfma16(f.a[r][1], f.b[1], acc2[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < RTC; ++r) {
+                acc[r] = mfma16(f.a[r][2], f.b[2], acc[r]);
+                acc2[r] = mfma16(f.a[r][3], f.b[3], acc2[r]);
+            }
+        });
+#pragma unroll
+    for (int r = 0; r < RTC; ++r) epi(rt0 + r, nb, acc[r] + acc2[r]);
+}
+
+template <int RT>
+__global__ __launch_bounds__(kThreads) void conv_gemm_kernel(bd_conv_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Kb = cdiv(a.K, 16), Nb = cdiv(a.N, 16);
+    float* X = smem;                                            // [RT][Kb] fragment tiles
+    int* rowoff = reinterpret_cast<int*>(smem + (size_t)RT * Kb * kFragFloats);   // output element offset per row, -1: none
+    const int M = a.imgs * a.gh * a.gw;
+    const int row0 = blockIdx.x * 16 * RT;
+    constexpr int kRows = 16 * RT;
+    constexpr int kTpr = kThreads / kRows;                      // threads per row of the gather
+    // ---- gather the A tile ----
+    {
+        const int tid = threadIdx.x;
+        const int r = tid / kTpr, j0 = tid - r * kTpr;
+        const int m = row0 + r;
+        const bool rok = m < M;
+        int img = 0, y = 0, x = 0;
+        if (rok) {
+            img = m / (a.gh * a.gw);
+            const int rem = m - img * a.gh * a.gw;
+            y = rem / a.gw;
+            x = rem - y * a.gw;
+        }
+        if (j0 == 0)
+            rowoff[r] = rok ? ((img * a.OH + y * a.osy + a.oy0) * a.OW + x * a.osx + a.ox0) * a.ldo : -1;
+        const int iy0 = y * a.sy + a.y0, ix0 = x * a.sx + a.x0;
+        const float* __restrict__ base = a.in + ((size_t)img * a.IH * a.IW) * a.C;
+        float* __restrict__ Xr = X + (size_t)(r >> 4) * Kb * kFragFloats;
+        const int rr = r & 15;
+        const int Kp = Kb * 16;
+        if (a.vec4) {      // C % 4 == 0: segments are 16-byte aligned runs
+            for (int k = 4 * j0; k < Kp; k += 4 * kTpr) {
+                floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (rok && k < a.K) {
+                    const int s = k / a.seglen, off = k - s * a.seglen;
+                    const int iy = iy0 + s * a.ss, ix = ix0 + (off >> a.cshift);
+                    if (!a.mask || (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW))
+                        v = *reinterpret_cast<const floatx4*>(base + ((size_t)iy * a.IW + ix0) * a.C + off);
+                }
+                *reinterpret_cast<floatx4*>(Xr + frag_idx(rr, k)) = v;
+            }
+        } else {
+            for (int k = j0; k < Kp; k += kTpr) {
+                float v = 0.f;
+                if (rok && k < a.K) {
+                    const int s = k / a.seglen, off = k - s * a.seglen;
+                    const int iy = iy0 + s * a.ss;
+                    v = base[((size_t)iy * a.IW + ix0) * a.C + off];       // (unmasked pattern only: host checks)
+                }
+                Xr[frag_idx(rr, k)] = v;
+            }
+        }
+    }
+    lds_barrier();
+    // ---- contraction: RT * Nb units dealt out contiguously over the waves ----
+    const int nrt = min(RT, cdiv(M - row0, 16));
+    const int tidc = bd_tid();
+    const int lane = tidc & 63, wave = bd_wave(tidc);
+    const int U = nrt * Nb;
+    const int ub = U / kWaves, urem = U - ub * kWaves;
+    const int u0 = wave * ub + min(wave, urem), u1 = u0 + ub + (wave < urem ? 1 : 0);
+    auto epi = [&](int rt, int nb, floatx4 acc) {
+        const int col = nb * 16 + (lane & 15);
+        if (col >= a.N) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int off = rowoff[rt * 16 + 4 * (lane >> 4) + r];
+            if (off >= 0) a.out[(size_t)off + col] = a.act ? elu(acc[r]) : acc[r];
+        }
+    };
+    int u = u0;
+    while (u < u1) {
+        const int nb = u / nrt, rt0 = u - nb * nrt;
+        const int cnt = min(min(u1 - u, nrt - rt0), 4);
+        if (cnt == 4) conv_segment<4>(X, Kb, a.w, a.bias, a.N, nb, rt0, epi);
+        else if (cnt == 3) conv_segment<3>(X, Kb, a.w, a.bias, a.N, nb, rt0, epi);
+        else if (cnt == 2) conv_segment<2>(X, Kb, a.w, a.bias, a.N, nb, rt0, epi);
+        else conv_segment<1>(X, Kb, a.w, a.bias, a.N, nb, rt0, epi);
+        u += cnt;
+    }
+}
+
+// Packed weights of one parity class of a T pattern from the stored (outer, ky, kx, inner) tensor:
+//   dst[n = inner][k = (a, b', outer)] = src[outer][py + 2a][px + 2(Tb-1-b')][inner]        (zero padded blocks)
+__global__ __launch_bounds__(256) void conv_pack_class_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                              int Couter, int Cinner, int ksz, int py, int px, int Ta,
+                                                              int Tb) {
+    const int K = Ta * Tb * Couter, N = Cinner;
+    const int Nb = (N + 15) >> 4, Kb = (K + 15) >> 4;
+    const int total = Nb * Kb * 64;
+    floatx4* __restrict__ d4 = reinterpret_cast<floatx4*>(dst);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int lane = e & 63, blk = e >> 6;
+        const int nb = blk / Kb, kb = blk - nb * Kb;
+        const int n = nb * 16 + (lane & 15);
+        const int k0 = kb * 16 + 4 * (lane >> 4);
+        floatx4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + i;
+            float xv = 0.f;
+            if (n < N && k < K) {
+                const int c = k % Couter, t = k / Couter;
+                const int bp = t % Tb, ta = t / Tb;
+                const int ky = py + 2 * ta, kx = px + 2 * (Tb - 1 - bp);
+                xv = src[(((size_t)c * ksz + ky) * ksz + kx) * Cinner + n];
+            }
+            v[i] = xv;
+        }
+        d4[e] = v;
+    }
+}
+
+// g <- g * ELU'(y) from the saved ELU outputs (in place): the pre-activation gradient of a conv layer
+__global__ __launch_bounds__(256) void elu_backward_kernel(float* __restrict__ g, const float* __restrict__ y, size_t n4) {
+    floatx4* __restrict__ g4 = reinterpret_cast<floatx4*>(g);
+    const floatx4* __restrict__ y4 = reinterpret_cast<const floatx4*>(y);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        floatx4 gv = g4[i];
+        const floatx4 yv = y4[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gv[j] *= elu_grad_from_out(yv[j]);
+        g4[i] = gv;
+    }
+}
+
+// (imgs, C, H*W) <-> (imgs, H*W, C)
+__global__ __launch_bounds__(256) void layout_kernel(const float* __restrict__ src, float* __restrict__ dst, int imgs, int C,
+                                                     int HW, int to_nhwc) {
+    const size_t total = (size_t)imgs * C * HW;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        // e indexes the DESTINATION (coalesced writes)
+        const size_t img = e / ((size_t)C * HW), rem = e - img * (size_t)C * HW;
+        if (to_nhwc) {
+            const int p = (int)(rem / C), c = (int)(rem - (size_t)p * C);
+            dst[e] = src[(img * C + c) * HW + p];
+        } else {
+            const int c = (int)(rem / HW), p = (int)(rem - (size_t)c * HW);
+            dst[e] = src[(img * HW + p) * C + c];
+        }
+    }
+}
+
+template <int RT>
+static int launch_conv(const bd_conv_args& a, hipStream_t s) {
+    const int Kb = cdiv(a.K, 16);
+    const size_t lds = ((size_t)RT * Kb * kFragFloats + 16 * RT) * sizeof(float);
+    BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_conv_gemm: K=%d needs %zu B of LDS at %d rows per workgroup", a.K, lds, 16 * RT);
+    if (lds > 64 * 1024 && allow_big_lds(conv_gemm_kernel<RT>)) return -1;
+    const long M = (long)a.imgs * a.gh * a.gw;
+    hipLaunchKernelGGL(conv_gemm_kernel<RT>, dim3((unsigned)cdiv((int)M, 16 * RT)), dim3(kThreads), lds, s, a);
+    BD_CHECK_LAUNCH("bd_conv_gemm");
+    return 0;
+}
+
+}  // namespace bd
+
+extern "C" {
+using namespace bd;
+
+int bd_conv_gemm(const bd_conv_args* a, void* stream) {
+    BD_REQUIRE(a && a->in && a->out && a->w && a->imgs > 0 && a->gh > 0 && a->gw > 0 && a->N > 0 && a->K > 0 &&
+                   a->nseg > 0 && a->seglen > 0 && a->nseg * a->seglen == a->K && a->C > 0 && a->IH > 0 && a->IW > 0 &&
+                   a->OH > 0 && a->OW > 0 && a->ldo >= a->N,
+               "bd_conv_gemm: bad arguments");
+    BD_REQUIRE((long)a->imgs * a->gh * a->gw < (1L << 31) && (long)a->imgs * a->OH * a->OW * a->ldo < (1L << 31),
+               "bd_conv_gemm: image batch too large for 32-bit element offsets");
+    BD_REQUIRE(!a->mask || (a->vec4 && (1 << a->cshift) == a->C), "bd_conv_gemm: masked gathers need C a power of two >= 4");
+    BD_REQUIRE(!a->vec4 || (a->C % 4 == 0 && a->seglen % 4 == 0), "bd_conv_gemm: vec4 gathers need C, seglen multiples of 4");
+    // rows per workgroup: as many 16-row tiles as LDS holds (<= 8): the packed weights (K x N) are streamed once per
+    // workgroup, 8*RT FLOP per byte.  BD_CONV_RT caps it (tuning).
+    const int Kb = cdiv(a->K, 16);
+    static const char* cap_env = getenv("BD_CONV_RT");
+    int rt = 8;
+    if (cap_env && atoi(cap_env) >= 1 && atoi(cap_env) < 8) rt = atoi(cap_env) >= 4 ? 4 : (atoi(cap_env) >= 2 ? 2 : 1);
+    while (rt > 1 && ((size_t)rt * Kb * kFragFloats + 16 * rt) * sizeof(float) > 150 * 1024) rt >>= 1;
+    switch (rt) {
+        case 8: return launch_conv<8>(*a, (hipStream_t)stream);
+        case 4: return launch_conv<4>(*a, (hipStream_t)stream);
+        case 2: return launch_conv<2>(*a, (hipStream_t)stream);
+        default: return launch_conv<1>(*a, (hipStream_t)stream);
+    }
+}
+
+int bd_conv_pack_class(const float* src, float* dst, int Couter, int Cinner, int ksz, int py, int px, int Ta, int Tb,
+                       void* stream) {
+    BD_REQUIRE(src && dst && Couter > 0 && Cinner > 0 && ksz > 0 && Ta > 0 && Tb > 0 && py + 2 * (Ta - 1) < ksz &&
+                   px + 2 * (Tb - 1) < ksz, "bd_conv_pack_class: bad arguments");
+    hipLaunchKernelGGL(conv_pack_class_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, src, dst, Couter, Cinner, ksz, py,
+                       px, Ta, Tb);
+    BD_CHECK_LAUNCH("bd_conv_pack_class");
+    return 0;
+}
+
+int bd_elu_backward(float* g, const float* y, size_t n, void* stream) {
+    BD_REQUIRE(g && y && n > 0 && (n & 3) == 0, "bd_elu_backward: bad arguments (n must be a multiple of 4)");
+    const size_t n4 = n >> 2;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(elu_backward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, y, n4);
+    BD_CHECK_LAUNCH("bd_elu_backward");
+    return 0;
+}
+
+int bd_image_layout(const float* src, float* dst, int imgs, int C, int HW, int to_nhwc, void* stream) {
+    BD_REQUIRE(src && dst && imgs > 0 && C > 0 && HW > 0, "bd_image_layout: bad arguments");
+    const size_t total = (size_t)imgs * C * HW;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(layout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, imgs, C, HW, to_nhwc);
+    BD_CHECK_LAUNCH("bd_image_layout");
+    return 0;
+}
+
+}  // extern "C"

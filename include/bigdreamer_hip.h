@@ -118,6 +118,33 @@ int bd_wgrad_plan(bd_wgrad_desc* descs_host, int n, int* total_blocks, int* tota
 int bd_wgrad_grouped(const bd_wgrad_desc* descs_dev, int n, int total_blocks, int total_red_blocks, float* ws,
                      void* stream);
 
+/* ---- conv stacks of the pixel configurations (CnnImageEncoder src/models.py:527-564, ObservationModel
+ * src/models.py:319-362; F.conv2d / F.conv_transpose2d and their autograd backward) as gather-GEMMs on NHWC images:
+ *   out[m][n] = act( sum_k A(m, k) W[n][k] + bias[n] ),  m = (img, y, x) over an imgs x gh x gw row grid,
+ *   A(m, k): s = k / seglen, off = k % seglen;  iy = y*sy + y0 + s*ss;  ix0 = x*sx + x0;
+ *            value = in[((img*IH + iy)*IW + ix0)*C + off]   (0 outside the image when mask = 1),
+ *   out row of m: out + ((img*OH + y*osy + oy0)*OW + x*osx + ox0)*ldo.
+ * Pattern F (stride-2 VALID conv forward, transposed-conv dgrad): nseg = k, seglen = k*C, sy = sx = 2, ss = 1, dense output.
+ * Pattern T (one parity class (py,px) of a stride-2 transposed conv forward / conv dgrad): nseg = Ta, seglen = Tb*C,
+ *   sy = sx = 1, ss = -1, x0 = -(Tb-1), mask = 1, osy = osx = 2, oy0 = py, ox0 = px; weights from bd_conv_pack_class. */
+typedef struct {
+    const float* in; float* out;
+    const float* w;       /* packed (bd_pack_weights / bd_conv_pack_class): out = N, in = K                 */
+    const float* bias;    /* [N] or NULL                                                                   */
+    int imgs, gh, gw, N, K;
+    int nseg, seglen, C, IH, IW, sy, y0, ss, sx, x0, mask, cshift, vec4;
+    int OH, OW, osy, oy0, osx, ox0, ldo;
+    int act;              /* BD_ACT_*                                                                      */
+} bd_conv_args;
+int bd_conv_gemm(const bd_conv_args* a, void* stream);
+/* dst (packed) [n = inner][k = (a, b', outer)] = src[outer][py+2a][px+2(Tb-1-b')][inner], src stored (outer, ky, kx, inner) */
+int bd_conv_pack_class(const float* src, float* dst, int Couter, int Cinner, int ksz, int py, int px, int Ta, int Tb,
+                       void* stream);
+/* g *= ELU'(y) in place from saved ELU outputs (n a multiple of 4) */
+int bd_elu_backward(float* g, const float* y, size_t n, void* stream);
+/* (imgs, C, HW) -> (imgs, HW, C) when to_nhwc, the reverse otherwise */
+int bd_image_layout(const float* src, float* dst, int imgs, int C, int HW, int to_nhwc, void* stream);
+
 /* ---- RSSM observe scan: TransitionModel.forward with embeddings (src/models.py:191-299) ------
  * One persistent launch walks all T steps; a workgroup owns 16 batch rows (rows are independent, so
  * there is no inter-workgroup synchronisation).  The prior head (src/models.py:256) does not feed the

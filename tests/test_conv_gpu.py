@@ -1,0 +1,87 @@
+"""GPU tests of the hand-written conv gather-GEMMs (csrc/conv.hip) against torch's F.conv2d / F.conv_transpose2d on the
+layer shapes of the reference's CnnImageEncoder / ObservationModel (src/models.py:319-362, 527-564)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fnn
+
+pytestmark = pytest.mark.gpu
+
+ENC = [(3, 32, 4, 64), (32, 64, 4, 31), (64, 128, 4, 14), (128, 256, 4, 6)]        # (Cin, Cout, k, input size)
+DEC = [(128, 64, 5, 5), (64, 32, 6, 13), (32, 3, 6, 30)]                           # ConvT after the 1x1 -> 5x5 layer
+
+
+def _close(got, want, tol=2e-5):
+    got, want = got.double().cpu().numpy(), want.double().cpu().numpy()
+    err = np.abs(got - want).max()
+    assert err <= tol * (1.0 + np.abs(want).max()), (err, np.abs(want).max())
+
+
+@pytest.mark.parametrize("Cin,Cout,k,size", ENC)
+def test_pattern_f_matches_conv2d_and_layout_roundtrip(Cin, Cout, k, size):
+    from big_dreamer_amd import _cabi as cabi, conv
+    g = torch.Generator(device="cuda").manual_seed(1)
+    imgs = 7
+    x = torch.randn(imgs, Cin, size, size, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) * 0.1
+    b = torch.randn(Cout, device="cuda", generator=g)
+    want = Fnn.elu(Fnn.conv2d(x, w, b, stride=2))
+    xs = conv.to_nhwc(x)
+    assert torch.equal(conv.to_nchw(xs), x)
+    stored = w.permute(0, 2, 3, 1).contiguous()                       # (co, ky, kx, ci)
+    K = k * k * Cin
+    wp = torch.zeros(cabi.packed_floats(Cout, K), device="cuda")
+    conv.pack_matrix(stored.view(Cout, K), wp, Cout, K)
+    OH = conv.conv_out(size, k)
+    out = torch.zeros(imgs, OH, OH, Cout, device="cuda")
+    conv.pattern_f(xs, out, wp, b, imgs, size, size, Cin, k, Cout, cabi.ACT_ELU)
+    _close(conv.to_nchw(out), want)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,size", DEC)
+def test_pattern_t_matches_conv_transpose2d(Cin, Cout, k, size):
+    from big_dreamer_amd import _cabi as cabi, conv
+    g = torch.Generator(device="cuda").manual_seed(2)
+    imgs = 5
+    x = torch.randn(imgs, Cin, size, size, device="cuda", generator=g)
+    w = torch.randn(Cin, Cout, k, k, device="cuda", generator=g) * 0.1
+    b = torch.randn(Cout, device="cuda", generator=g)
+    want = Fnn.conv_transpose2d(x, w, b, stride=2)
+    stored = w.permute(0, 2, 3, 1).contiguous()                       # (ci, ky, kx, co)
+    packs = [torch.zeros(n, device="cuda") for n in conv.class_pack_floats(Cin, Cout, k)]
+    conv.pack_classes(stored, packs, Cin, Cout, k)
+    OH = conv.convT_out(size, k)
+    out = torch.full((imgs, OH, OH, Cout), float("nan"), device="cuda")       # every pixel must be written
+    conv.pattern_t(conv.to_nhwc(x), out, packs, b, imgs, size, size, Cin, k, Cout, OH, OH, cabi.ACT_NONE)
+    _close(conv.to_nchw(out), want)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,size", ENC[1:])
+def test_conv2d_dgrad_is_pattern_t_and_convT_dgrad_is_pattern_f(Cin, Cout, k, size):
+    from big_dreamer_amd import _cabi as cabi, conv
+    g = torch.Generator(device="cuda").manual_seed(3)
+    imgs = 4
+    x = torch.randn(imgs, Cin, size, size, device="cuda", generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) * 0.1
+    y = Fnn.conv2d(x, w, None, stride=2)
+    gy = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    stored = w.permute(0, 2, 3, 1).contiguous()                       # (co, ky, kx, ci): outer = co = K side of the dgrad
+    packs = [torch.zeros(n, device="cuda") for n in conv.class_pack_floats(Cout, Cin, k)]
+    conv.pack_classes(stored, packs, Cout, Cin, k)
+    OH = conv.conv_out(size, k)
+    out = torch.full((imgs, size, size, Cin), float("nan"), device="cuda")
+    conv.pattern_t(conv.to_nhwc(gy), out, packs, None, imgs, OH, OH, Cout, k, Cin, size, size, cabi.ACT_NONE)
+    _close(conv.to_nchw(out), gx)
+    # transposed convolution with the same tensor as its (ci=Cout, co=Cin) weight: dgrad = strided conv of the gradient
+    xt = torch.randn(imgs, Cout, OH, OH, device="cuda", generator=g, requires_grad=True)
+    yt = Fnn.conv_transpose2d(xt, w, None, stride=2)                  # w viewed as (ci=Cout, co=Cin, k, k)
+    gyt = torch.randn_like(yt)
+    (gxt,) = torch.autograd.grad(yt, xt, gyt)
+    Kt = k * k * Cin
+    wp = torch.zeros(cabi.packed_floats(Cout, Kt), device="cuda")
+    conv.pack_matrix(stored.view(Cout, Kt), wp, Cout, Kt)             # stored = (ci_T, ky, kx, co_T) for the transposed conv
+    HT = conv.convT_out(OH, k)
+    outt = torch.zeros(imgs, OH, OH, Cout, device="cuda")
+    conv.pattern_f(conv.to_nhwc(gyt), outt, wp, None, imgs, HT, HT, Cin, k, Cout, cabi.ACT_NONE)
+    _close(conv.to_nchw(outt), gxt)
