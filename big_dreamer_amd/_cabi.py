@@ -55,7 +55,9 @@ class WgradDesc(C.Structure):
     _fields_ = [("dpre", P), ("ldp", I32), ("act1", P), ("lda1", I32), ("M1", I32), ("act2", P), ("lda2", I32),
                 ("M", I32), ("N", I32), ("K", I32), ("dW", P), ("ldw", I32), ("db", P),
                 ("splits", I32), ("rows_per", I32), ("tiles_n", I32), ("tiles_k", I32), ("block_begin", I32),
-                ("red_begin", I32), ("ws_off", C.c_ulonglong)]
+                ("red_begin", I32), ("ws_off", C.c_ulonglong),
+                ("g_nseg", I32), ("g_seglen", I32), ("g_gh", I32), ("g_gw", I32), ("g_IH", I32), ("g_IW", I32), ("g_C", I32),
+                ("g_pad", I32)]
 
 
 def _ptr_fields(names):

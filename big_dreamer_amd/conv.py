@@ -105,3 +105,32 @@ def to_nchw(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty(imgs, Cc, H, W, dtype=torch.float32, device=x.device)
     cabi.check(lib.bd_image_layout(ptr(x.contiguous()), ptr(out), imgs, Cc, H * W, 0, cabi.stream()))
     return out
+
+
+def wgrad_desc(dpre2d: torch.Tensor, N: int, act_img: torch.Tensor, imgs: int, gh: int, gw: int, IH: int, IW: int, Cimg: int,
+               k: int, dW: torch.Tensor, db) -> "cabi.WgradDesc":
+    """Descriptor of a conv weight-gradient GEMM: dW[N][(ky, kx, c)] = sum_m dpre[m][n] * window_F(act_img)(m, (ky, kx, c)),
+    m over imgs x gh x gw (gh, gw = the stride-2 VALID output grid of the IH x IW x Cimg image), db[n] = sum_m dpre[m][n].
+    Conv2d: dpre = gradient of the conv output (N = co), act_img = the conv input.  ConvTranspose2d: dpre = the layer's
+    INPUT rows (N = ci), act_img = gradient of its output -- the result is the (ci, ky, kx, co) stored layout."""
+    dsc = cabi.WgradDesc()
+    M = imgs * gh * gw
+    dsc.dpre, dsc.ldp = ptr(dpre2d), N
+    dsc.act1, dsc.lda1, dsc.M1, dsc.act2, dsc.lda2 = ptr(act_img), 0, M, None, 0
+    dsc.M, dsc.N, dsc.K = M, N, k * k * Cimg
+    dsc.dW, dsc.ldw, dsc.db = ptr(dW), k * k * Cimg, ptr(db)
+    dsc.g_nseg, dsc.g_seglen, dsc.g_gh, dsc.g_gw, dsc.g_IH, dsc.g_IW, dsc.g_C = k, k * Cimg, gh, gw, IH, IW, Cimg
+    return dsc
+
+
+def run_wgrad(descs: list) -> None:
+    """Plan + launch a list of descriptors once (tests / one-off use; the engine caches tables)."""
+    n = len(descs)
+    arr = (cabi.WgradDesc * n)(*descs)
+    tb, tr, wsf = C.c_int(0), C.c_int(0), C.c_size_t(0)
+    cabi.check(lib.bd_wgrad_plan(arr, n, C.byref(tb), C.byref(tr), C.byref(wsf)))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    ws = torch.zeros(max(1, wsf.value), dtype=torch.float32, device=dev)
+    cabi.check(lib.bd_wgrad_grouped(table.data_ptr(), n, tb.value, tr.value, ptr(ws), cabi.stream()))
+    torch.cuda.current_stream().synchronize()

@@ -205,12 +205,28 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
             float* A = P + kWRows * kWLd;
             if (m < m_end) {
                 const float* prow = d.dpre + (size_t)m * d.ldp + n0;
-                const float* arow = (m < d.M1 ? d.act1 + (size_t)m * d.lda1 : d.act2 + (size_t)(m - d.M1) * d.lda2) + k0;
+                if (d.g_nseg > 0) {       // gathered operand: the k x k x C window of output pixel m (conv.hip, pattern F)
+                    const int img = m / (d.g_gh * d.g_gw), rem = m - img * d.g_gh * d.g_gw;
+                    const int y = rem / d.g_gw, x = rem - y * d.g_gw;
+                    const float* gbase = d.act1 + (((size_t)img * d.g_IH + 2 * y) * d.g_IW + 2 * x) * d.g_C;
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const int c = lane + 64 * cc;
-                    if (c < ncol) __builtin_amdgcn_global_load_lds((glb_ptr_t)(prow + c), (lds_ptr_t)(P + 64 * cc), 4, 0, 0);
-                    if (c < kcol) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arow + c), (lds_ptr_t)(A + 64 * cc), 4, 0, 0);
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int c = lane + 64 * cc;
+                        if (c < ncol) __builtin_amdgcn_global_load_lds((glb_ptr_t)(prow + c), (lds_ptr_t)(P + 64 * cc), 4, 0, 0);
+                        if (c < kcol) {
+                            const int k = k0 + c, sgm = k / d.g_seglen, off = k - sgm * d.g_seglen;
+                            __builtin_amdgcn_global_load_lds((glb_ptr_t)(gbase + (size_t)sgm * d.g_IW * d.g_C + off),
+                                                             (lds_ptr_t)(A + 64 * cc), 4, 0, 0);
+                        }
+                    }
+                } else {
+                    const float* arow = (m < d.M1 ? d.act1 + (size_t)m * d.lda1 : d.act2 + (size_t)(m - d.M1) * d.lda2) + k0;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int c = lane + 64 * cc;
+                        if (c < ncol) __builtin_amdgcn_global_load_lds((glb_ptr_t)(prow + c), (lds_ptr_t)(P + 64 * cc), 4, 0, 0);
+                        if (c < kcol) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arow + c), (lds_ptr_t)(A + 64 * cc), 4, 0, 0);
+                    }
                 }
             } else {
 #pragma unroll
@@ -361,8 +377,13 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
         BD_REQUIRE(d.dpre && d.act1 && d.dW && d.M > 0 && d.N > 0 && d.K > 0 && d.M1 >= 0 && d.M1 <= d.M,
                    "bd_wgrad_plan: descriptor %d is malformed", i);
         BD_REQUIRE(d.M1 == d.M || d.act2, "bd_wgrad_plan: descriptor %d needs a second activation source", i);
-        BD_REQUIRE(d.ldp >= d.N && d.lda1 >= d.K && d.ldw >= d.K && (d.M1 == d.M || d.lda2 >= d.K),
+        BD_REQUIRE(d.ldp >= d.N && (d.g_nseg > 0 || d.lda1 >= d.K) && d.ldw >= d.K && (d.M1 == d.M || d.lda2 >= d.K),
                    "bd_wgrad_plan: descriptor %d has a leading dimension that is too small", i);
+        if (d.g_nseg > 0)
+            BD_REQUIRE(wgrad_wide() && d.M1 == d.M && d.g_seglen > 0 && d.g_nseg * d.g_seglen == d.K && d.g_gh > 0 &&
+                           d.g_gw > 0 && d.M % (d.g_gh * d.g_gw) == 0 && d.g_C > 0 && 2 * (d.g_gh - 1) + d.g_nseg <= d.g_IH &&
+                           (2 * (d.g_gw - 1)) * d.g_C + d.g_seglen <= d.g_IW * d.g_C,
+                       "bd_wgrad_plan: descriptor %d has an inconsistent gather geometry", i);
         const int hb = d.db != nullptr;
         if (wgrad_wide()) {
             // tiles of <= 13 x 13 16-blocks, balanced; the row split is chosen below for the whole launch

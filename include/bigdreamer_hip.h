@@ -113,6 +113,10 @@ typedef struct {
     /* filled by bd_wgrad_plan */
     int splits, rows_per, tiles_n, tiles_k, block_begin, red_begin;
     unsigned long long ws_off;
+    /* optional gathered `act` (conv weight gradients, pattern F of bd_conv_gemm): when g_nseg > 0, row m = (img, y, x)
+     * over g_gh x g_gw per image takes act(m, k) = act1[((img*g_IH + 2y + s)*g_IW + 2x)*g_C + off], s = k / g_seglen,
+     * off = k % g_seglen (K = g_nseg * g_seglen; lda1 / act2 unused, M1 = M). */
+    int g_nseg, g_seglen, g_gh, g_gw, g_IH, g_IW, g_C, g_pad;
 } bd_wgrad_desc;
 int bd_wgrad_plan(bd_wgrad_desc* descs_host, int n, int* total_blocks, int* total_red_blocks, size_t* ws_floats);
 int bd_wgrad_grouped(const bd_wgrad_desc* descs_dev, int n, int total_blocks, int total_red_blocks, float* ws,

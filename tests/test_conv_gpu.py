@@ -85,3 +85,35 @@ def test_conv2d_dgrad_is_pattern_t_and_convT_dgrad_is_pattern_f(Cin, Cout, k, si
     outt = torch.zeros(imgs, OH, OH, Cout, device="cuda")
     conv.pattern_f(conv.to_nhwc(gyt), outt, wp, None, imgs, HT, HT, Cin, k, Cout, cabi.ACT_NONE)
     _close(conv.to_nchw(outt), gxt)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,size", ENC + [(64, 32, 6, 30), (32, 3, 6, 64)])
+def test_gathered_wgrad_matches_conv_weight_gradients(Cin, Cout, k, size):
+    """Conv2d: dW, db from (dOut rows, input windows); ConvTranspose2d with the same geometry: (input rows, dOut windows)."""
+    from big_dreamer_amd import conv
+    g = torch.Generator(device="cuda").manual_seed(4)
+    imgs = 6
+    OH = conv.conv_out(size, k)
+    x = torch.randn(imgs, Cin, size, size, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) * 0.1
+    gy = torch.randn(imgs, Cout, OH, OH, device="cuda", generator=g)
+    _, gw_ref, gb_ref = torch.ops.aten.convolution_backward(gy, x, w, [Cout], [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
+                                                            [False, True, True])
+    dW = torch.zeros(Cout, k, k, Cin, device="cuda")
+    db = torch.zeros(Cout, device="cuda")
+    gys = conv.to_nhwc(gy).view(imgs * OH * OH, Cout)
+    xs = conv.to_nhwc(x)                      # (descriptors hold raw pointers: keep the operands alive)
+    conv.run_wgrad([conv.wgrad_desc(gys, Cout, xs, imgs, OH, OH, size, size, Cin, k, dW, db)])
+    _close(dW.permute(0, 3, 1, 2), gw_ref, 1e-4)
+    _close(db, gb_ref, 1e-4)
+    # transposed conv (ci_T = Cout -> co_T = Cin) from OH x OH to size' = 2(OH-1)+k: weight gradient in (ci, ky, kx, co)
+    HT = conv.convT_out(OH, k)
+    xt = torch.randn(imgs, Cout, OH, OH, device="cuda", generator=g)
+    gyt = torch.randn(imgs, Cin, HT, HT, device="cuda", generator=g)
+    _, gwt_ref, _ = torch.ops.aten.convolution_backward(gyt, xt, w, None, [2, 2], [0, 0], [1, 1], True, [0, 0], 1,
+                                                        [False, True, False])
+    dWt = torch.zeros(Cout, k, k, Cin, device="cuda")
+    xts = conv.to_nhwc(xt).view(imgs * OH * OH, Cout)
+    gyts = conv.to_nhwc(gyt)
+    conv.run_wgrad([conv.wgrad_desc(xts, Cout, gyts, imgs, OH, OH, HT, HT, Cin, k, dWt, None)])
+    _close(dWt.permute(0, 3, 1, 2), gwt_ref, 1e-4)
