@@ -147,6 +147,8 @@ _SIGS = {
     "bd_conv_pack_class": (I32, [P, P, I32, I32, I32, I32, I32, I32, I32, P]),
     "bd_elu_backward": (I32, [P, P, C.c_size_t, P]),
     "bd_image_layout": (I32, [P, P, I32, I32, I32, I32, P]),
+    "bd_colsum_ws_floats": (C.c_size_t, [I32]),
+    "bd_colsum": (I32, [P, C.c_size_t, I32, P, P, P]),
 }
 
 for _name, (_res, _args) in _SIGS.items():

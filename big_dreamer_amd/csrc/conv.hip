@@ -211,6 +211,43 @@ __global__ __launch_bounds__(256) void layout_kernel(const float* __restrict__ s
     }
 }
 
+// Column sums of an [M x N] row-major matrix (bias gradient of a transposed-conv layer: sum over all output pixels),
+// N <= 256: stage 1 = per-workgroup partial sums over a contiguous slab of rows, stage 2 = fixed-order sum of the
+// partials (bitwise reproducible).
+constexpr int kColsumBlocks = 1024;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ rows, size_t M, int N, int Np,
+                                                             float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int c = threadIdx.x & (Np - 1), r0 = threadIdx.x / Np, rstep = 256 / Np;
+    const size_t per = (M + gridDim.x - 1) / gridDim.x;
+    const size_t m0 = (size_t)blockIdx.x * per, m1 = m0 + per < M ? m0 + per : M;
+    float acc = 0.f;
+    if (c < N)
+        for (size_t m = m0 + r0; m < m1; m += rstep) acc += rows[m * N + c];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < Np) {
+        float t = 0.f;
+        for (int r = 0; r < rstep; ++r) t += red[r * Np + threadIdx.x];
+        if (threadIdx.x < N) partial[(size_t)blockIdx.x * N + threadIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int N,
+                                                           float* __restrict__ out) {
+    // one workgroup per column; 256 threads take every 256th partial, then a fixed-order tree (reproducible)
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float t = 0.f;
+    for (int b = threadIdx.x; b < nblocks; b += 256) t += partial[(size_t)b * N + c];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = red[0];
+}
+
 template <int RT>
 static int launch_conv(const bd_conv_args& a, hipStream_t s) {
     const int Kb = cdiv(a.K, 16);
@@ -268,6 +305,20 @@ int bd_elu_backward(float* g, const float* y, size_t n, void* stream) {
     const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(elu_backward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, y, n4);
     BD_CHECK_LAUNCH("bd_elu_backward");
+    return 0;
+}
+
+size_t bd_colsum_ws_floats(int N) { return (size_t)bd::kColsumBlocks * (size_t)N; }
+
+int bd_colsum(const float* rows, size_t M, int N, float* out, float* ws, void* stream) {
+    BD_REQUIRE(rows && out && ws && M > 0 && N > 0 && N <= 256, "bd_colsum: bad arguments (N <= 256)");
+    int Np = 1;
+    while (Np < N) Np <<= 1;
+    const int nb = (int)(M < (size_t)kColsumBlocks * 64 ? (M + 63) / 64 : kColsumBlocks);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows, M, N, Np, ws);
+    BD_CHECK_LAUNCH("bd_colsum");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, ws, nb, N, out);
+    BD_CHECK_LAUNCH("bd_colsum(final)");
     return 0;
 }
 

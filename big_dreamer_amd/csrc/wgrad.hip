@@ -372,6 +372,36 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
         rows_wide = 128;
         while (wgs(rows_wide) > 256 && rows_wide < (1 << 20)) rows_wide += kWRows;
     }
+    // Launches that contain conv weight gradients (gathered operand) mix row counts from 2 450 to 2.4 M: one row count
+    // for all would leave a single workgroup streaming millions of rows.  There every GEMM gets rows_per = T / cost,
+    // cost = blocks on the fullest SIMD of its tile + 12 (per-stage DMA / barrier overhead in the same unit), with T
+    // chosen for about R rounds of 256 workgroups, R = total work / (256 x 1024 rows of a full 13 x 13 tile).
+    bool any_gather = false;
+    for (int i = 0; i < n; ++i) any_gather = any_gather || descs[i].g_nseg > 0;
+    auto tile_cost = [](int nb, int kb) {
+        const int hn = (nb + 1) >> 1, kq = kb >> 2, kr = kb & 3;
+        const int c = hn * ((kq + (0 < kr ? 1 : 0)) + (kq + (2 < kr ? 1 : 0)));
+        return (c > 0 ? c : 1) + 12;
+    };
+    auto desc_geo = [&](const bd_wgrad_desc& d, int* tiles, int* cost) {
+        const int NB = cdiv(d.N, 16), KB = cdiv(d.K + (d.db != nullptr), 16);
+        const int tn = cdiv(NB, kWB), tk = cdiv(KB, kWB);
+        *tiles = tn * tk;
+        *cost = tile_cost(cdiv(NB, tn), cdiv(KB, tk));
+    };
+    double budget = 0.0;
+    if (wgrad_wide() && any_gather) {
+        double W = 0.0;
+        for (int i = 0; i < n; ++i) {
+            int t, c;
+            desc_geo(descs[i], &t, &c);
+            W += (double)t * (descs[i].M > 0 ? descs[i].M : 1) * c;
+        }
+        double R = W / (256.0 * 1024.0 * 61.0);
+        if (R < 1.0) R = 1.0;
+        if (R > 24.0) R = 24.0;
+        budget = W / (256.0 * (double)(int)(R + 0.999));
+    }
     for (int i = 0; i < n; ++i) {
         bd_wgrad_desc& d = descs[i];
         BD_REQUIRE(d.dpre && d.act1 && d.dW && d.M > 0 && d.N > 0 && d.K > 0 && d.M1 >= 0 && d.M1 <= d.M,
@@ -390,6 +420,13 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
             d.tiles_n = cdiv(cdiv(d.N, 16), kWB);
             d.tiles_k = cdiv(cdiv(d.K + hb, 16), kWB);
             d.rows_per = rows_wide;
+            if (budget > 0.0) {
+                int t, c;
+                desc_geo(d, &t, &c);
+                long r = (long)(budget / c);
+                r = (r / kWRows) * kWRows;
+                d.rows_per = (int)(r < 4 * kWRows ? 4 * kWRows : (r > (1 << 22) ? (1 << 22) : r));
+            }
             d.splits = cdiv(d.M, d.rows_per);
         } else {
             d.tiles_n = cdiv(d.N, kWT);

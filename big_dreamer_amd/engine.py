@@ -45,9 +45,15 @@ N_SLOTS = 16
 
 
 class ParamGroup:
-    """Flat parameter / gradient / Adam-moment buffers of one optimiser, with named views."""
+    """Flat parameter / gradient / Adam-moment buffers of one optimiser, with named views.
 
-    def __init__(self, specs: List[Tuple[str, str, Tuple[int, ...]]], device, with_opt: bool = True):
+    With `conv_storage`, 4-D (convolution) tensors are STORED permuted (d0, d2, d3, d1) -- Conv2d (co, ky, kx, ci),
+    ConvTranspose2d (ci, ky, kx, co): the layout the hand-written conv kernels use as plain [N][K] matrices
+    (csrc/conv.hip) -- while `p` / `g` stay views with the reference's logical shape (state_dict, tests); `ps` / `gs`
+    are the contiguous storage views.  Clip, Adam and the all-reduce act on the flat buffers and do not care."""
+
+    def __init__(self, specs: List[Tuple[str, str, Tuple[int, ...]]], device, with_opt: bool = True,
+                 conv_storage: bool = False):
         self.specs = specs
         n = sum(int(np.prod(s)) for _, _, s in specs)
         self.numel = n
@@ -58,12 +64,21 @@ class ParamGroup:
         self.step = 0
         self.p: Dict[Tuple[str, str], torch.Tensor] = {}
         self.g: Dict[Tuple[str, str], torch.Tensor] = {}
+        self.ps: Dict[Tuple[str, str], torch.Tensor] = {}
+        self.gs: Dict[Tuple[str, str], torch.Tensor] = {}
         off = 0
         for mod, name, shape in specs:
             k = int(np.prod(shape))
-            self.p[(mod, name)] = self.flat[off:off + k].view(shape)
+            perm = conv_storage and len(shape) == 4
+            sshape = (shape[0], shape[2], shape[3], shape[1]) if perm else shape
+
+            def views(buf):
+                st = buf[off:off + k].view(sshape)
+                return st, (st.permute(0, 3, 1, 2) if perm else st)
+
+            self.ps[(mod, name)], self.p[(mod, name)] = views(self.flat)
             if with_opt:
-                self.g[(mod, name)] = self.grad[off:off + k].view(shape)
+                self.gs[(mod, name)], self.g[(mod, name)] = views(self.grad)
             off += k
 
 
@@ -76,9 +91,11 @@ class WgradBatch:
         self.items: List[tuple] = []
         self._cache: Dict[tuple, tuple] = {}
 
-    def add(self, dpre, ldp, act, lda, M, N, K, dW, ldw, db=None, act2=None, lda2=0, M1=None) -> None:
+    def add(self, dpre, ldp, act, lda, M, N, K, dW, ldw, db=None, act2=None, lda2=0, M1=None, gather=None) -> None:
+        """gather = (nseg, seglen, gh, gw, IH, IW, C): `act` is an NHWC image and row m takes its stride-2 window
+        (conv weight gradients, include/bigdreamer_hip.h)."""
         self.items.append((ptr(dpre), ldp, ptr(act), lda, M if M1 is None else M1, ptr(act2), lda2, M, N, K, ptr(dW), ldw,
-                           ptr(db)))
+                           ptr(db), tuple(gather) if gather else (0, 0, 0, 0, 0, 0, 0)))
 
     def run(self) -> None:
         eng = self.eng
@@ -89,7 +106,9 @@ class WgradBatch:
             descs = (cabi.WgradDesc * n)()
             for i, it in enumerate(self.items):
                 (descs[i].dpre, descs[i].ldp, descs[i].act1, descs[i].lda1, descs[i].M1, descs[i].act2, descs[i].lda2,
-                 descs[i].M, descs[i].N, descs[i].K, descs[i].dW, descs[i].ldw, descs[i].db) = it
+                 descs[i].M, descs[i].N, descs[i].K, descs[i].dW, descs[i].ldw, descs[i].db) = it[:13]
+                (descs[i].g_nseg, descs[i].g_seglen, descs[i].g_gh, descs[i].g_gw, descs[i].g_IH, descs[i].g_IW,
+                 descs[i].g_C) = it[13]
             tb, tr, wsf = C.c_int(0), C.c_int(0), C.c_size_t(0)
             cabi.check(lib.bd_wgrad_plan(descs, n, C.byref(tb), C.byref(tr), C.byref(wsf)))
             # (a pageable H2D copy synchronises with the device: tables are cached per operand-pointer set -- the
@@ -121,8 +140,13 @@ class DreamerEngine:
                                process_group, phase_groups)
         d = dims
         shapes = param_shapes(d)
+        # pixel mode: BD_CONV=hip runs the conv stacks on this library's gather-GEMM kernels (csrc/conv.hip,
+        # conv_stack.py; parity-green, 25.8 ms/step at configs[2]); the default keeps them on MIOpen through torch
+        # autograd, the measured incumbent (17.9 ms/step) -- see DESIGN.md section 5, row R11
+        self.conv_hip = self.pixel and os.environ.get("BD_CONV", "miopen") == "hip"
         self.groups = {
-            "model": ParamGroup([(m, n, s) for m in MODEL_MODULES for n, s in shapes[m]], self.dev),
+            "model": ParamGroup([(m, n, s) for m in MODEL_MODULES for n, s in shapes[m]], self.dev,
+                                conv_storage=self.conv_hip),
             "actor": ParamGroup([("actor", n, s) for n, s in shapes["actor"]], self.dev),
             "critic": ParamGroup([("critic", n, s) for n, s in shapes["critic"]], self.dev),
             "critic_target": ParamGroup([("critic_target", n, s) for n, s in shapes["critic"]], self.dev, False),
@@ -178,6 +202,10 @@ class DreamerEngine:
         self._timers_on, self._timer_every, self._timer_tick = False, 1, 0
         self._timer_events: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
         self._build_pack_tables()
+        self.conv = None
+        if self.conv_hip:
+            from .conv_stack import ConvStacks
+            self.conv = ConvStacks(self)
         for g in ("model", "actor", "critic", "critic_target"):
             self.pack(g)
 
@@ -220,6 +248,13 @@ class DreamerEngine:
 
     def G(self, mod: str, name: str) -> torch.Tensor:
         return self.groups[self._mod_group[mod]].g[(mod, name)]
+
+    def Ws(self, mod: str, name: str) -> torch.Tensor:
+        """Contiguous STORAGE view of a parameter (differs from W() for conv tensors in conv_hip mode)."""
+        return self.groups[self._mod_group[mod]].ps[(mod, name)]
+
+    def Gs(self, mod: str, name: str) -> torch.Tensor:
+        return self.groups[self._mod_group[mod]].gs[(mod, name)]
 
     def load_params(self, params: dict) -> None:
         for mod, sd in params.items():
@@ -302,6 +337,8 @@ class DreamerEngine:
     def pack(self, group: str) -> None:
         raw, n, _ = self._pack_tables[group]
         cabi.check(lib.bd_pack_weights(raw.data_ptr(), n, cabi.stream()))
+        if group == "model" and self.conv is not None:
+            self.conv.pack()
 
     # ------------------------------------------------------------------------------------------ kernels
     def _dense_spec(self, mod: str, prefix: str, in_width: int, out_width: int):
@@ -310,23 +347,26 @@ class DreamerEngine:
         return [(f"{prefix}{l}", self.W(mod, f"model.{2 * l}.bias"), sizes[l + 1], sizes[l],
                  cabi.ACT_ELU if l < DENSE_LAYERS else cabi.ACT_NONE) for l in range(DENSE_LAYERS + 1)]
 
-    def mlp_forward(self, M, in0, ld0, w0, layers, saves, out, ldo, in1=None, ld1=0, w1=0) -> None:
+    def mlp_forward(self, M, in0, ld0, w0, layers, saves, out, ldo, in1=None, ld1=0, w1=0, raw_packs=False) -> None:
+        """layers: [(packed-weight key | packed tensor when raw_packs, bias, N, K, act)]."""
         a = cabi.MlpFwdArgs()
         a.M, a.in0, a.ld0, a.w0 = M, ptr(in0), ld0, w0
         a.in1, a.ld1, a.w1 = ptr(in1), ld1, w1
         a.n_layers = len(layers)
         for i, (key, bias, N, K, act) in enumerate(layers):
-            a.layer[i] = cabi.Layer(ptr(self.pk[key]), ptr(bias), N, K, act, ptr(saves[i]) if saves else None)
+            a.layer[i] = cabi.Layer(ptr(key if raw_packs else self.pk[key]), ptr(bias), N, K, act,
+                                    ptr(saves[i]) if saves else None)
         a.out, a.ldo = ptr(out), ldo
         cabi.check(lib.bd_mlp_forward(C.byref(a), cabi.stream()))
 
     def mlp_backward(self, M, dout, lddo, layers, saves, dpres, din0=None, ld0=0, w0=0, din1=None, ld1=0, w1=0,
-                     accumulate=False, dout_scale=1.0) -> None:
+                     accumulate=False, dout_scale=1.0, raw_packs=False) -> None:
+        """layers as in mlp_forward; with raw_packs the first entry is the packed TRANSPOSED weight tensor."""
         a = cabi.MlpBwdArgs()
         a.M, a.dout, a.lddo, a.dout_scale = M, ptr(dout), lddo, dout_scale
         a.n_layers = len(layers)
         for i, (key, _bias, N, K, act) in enumerate(layers):
-            wt = self.pk.get(key + ".T")
+            wt = key if raw_packs else self.pk.get(key + ".T")
             a.layer[i] = cabi.LayerBwd(ptr(wt) if wt is not None else None,
                                        ptr(saves[i]) if (saves and saves[i] is not None) else None, N, K, act,
                                        ptr(dpres[i]) if (dpres and dpres[i] is not None) else None)
@@ -393,6 +433,11 @@ class DreamerEngine:
         """CnnImageEncoder (src/models.py:527-564) on (M,3,64,64) + the hoisted posterior projection (HIP)."""
         d = self.d
         M = obs4d.shape[0]
+        if self.conv is not None:        # hand-written gather-GEMM stack (conv_stack.py)
+            emb = self.conv.encode(obs4d.float(), tag="" if grad else "api_")
+            pre = self.buf("pre_emb" if grad else "api_cv_pre_emb", M, d.Hd)
+            self.mlp_forward(M, emb, d.E, d.E, [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)], None, pre, d.Hd)
+            return emb, pre
         with torch.set_grad_enabled(grad):
             w = self._leaf_params("encoder") if grad else self.state_dict("encoder")
             x = obs4d
@@ -409,6 +454,9 @@ class DreamerEngine:
 
     def decode_pixels(self, feat: torch.Tensor, grad: bool = True) -> torch.Tensor:
         """ObservationModel (src/models.py:319-362): (M, Be+S) -> (M,3,64,64)."""
+        if self.conv is not None:        # API use (ObservationModel.forward): NHWC prediction back to the reference's NCHW
+            from . import conv as _conv
+            return _conv.to_nchw(self.conv.decode(feat.contiguous().float(), tag="api_"))
         with torch.set_grad_enabled(grad):
             w = self._leaf_params("observation_model") if grad else self.state_dict("observation_model")
             f = feat.detach().requires_grad_(grad)
@@ -639,7 +687,10 @@ class DreamerEngine:
                                     feat_tag=feat_tag)
         with self.span("wm_heads_fwd"):
             _, pm, ps = self.prior_head(feat, N, noise["obs_prior"])
-            if self.pixel:
+            if self.conv is not None:
+                om_out, om_acts, om_layers = self.conv.decode(feat).view(N, d.O), None, None
+                obs_t = self.conv.acts_enc[0].view(N, d.O)      # the same images in the NHWC order of the prediction
+            elif self.pixel:
                 om_out, om_acts, om_layers = self.decode_pixels(feat).detach().view(N, d.O), None, None
             else:
                 om_out, om_acts, om_layers = self.dense_forward("observation_model", "obs", "om", feat, F, N, d.O)
@@ -664,7 +715,11 @@ class DreamerEngine:
         # ---- backward of the world model ----
         dfeat = self.buf("dfeat", N, F)
         rw_dpre = [self.buf(f"rw_dpre{l}", N, d.Hd) for l in range(DENSE_LAYERS)] + [d_rw]
-        if self.pixel:
+        if self.conv is not None:
+            self.mlp_backward(N, d_rw, 1, rw_layers, rw_acts + [None], rw_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F)
+            with self.span("decoder_bwd"):
+                self.conv.backward_decoder(d_om.view(N, 64, 64, 3), feat, dfeat, self._wbatch["model"])
+        elif self.pixel:
             self.mlp_backward(N, d_rw, 1, rw_layers, rw_acts + [None], rw_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F)
             with self.span("decoder_bwd"):
                 pred, wdec, fleaf = self._dec_graph
@@ -715,11 +770,14 @@ class DreamerEngine:
             self.mlp_backward(N, d_q1, d.Hd, [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)], [None], [None], din0=d_emb, ld0=d.E,
                               w0=d.E)
             with self.span("encoder_bwd"):
-                x, wenc = self._enc_graph
-                names = list(wenc)
-                for n, g in zip(names, torch.autograd.grad(x, [wenc[n] for n in names], d_emb)):
-                    self.G("encoder", n).copy_(g)
-                self._enc_graph = None
+                if self.conv is not None:
+                    self.conv.backward_encoder(d_emb, self._wbatch["model"])
+                else:
+                    x, wenc = self._enc_graph
+                    names = list(wenc)
+                    for n, g in zip(names, torch.autograd.grad(x, [wenc[n] for n in names], d_emb)):
+                        self.G("encoder", n).copy_(g)
+                    self._enc_graph = None
         else:
             enc_layers = self._dense_spec("encoder", "enc", d.O, d.E) + [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)]
             enc_acts = [self._buf[f"enc_act{l}"] for l in range(DENSE_LAYERS)]

@@ -146,6 +146,10 @@ int bd_conv_pack_class(const float* src, float* dst, int Couter, int Cinner, int
                        void* stream);
 /* g *= ELU'(y) in place from saved ELU outputs (n a multiple of 4) */
 int bd_elu_backward(float* g, const float* y, size_t n, void* stream);
+/* out[n] = sum_m rows[m][n] of an [M x N] row-major matrix, N <= 256 (bias gradient of a transposed-conv layer);
+ * ws: bd_colsum_ws_floats(N) floats; fixed summation order */
+size_t bd_colsum_ws_floats(int N);
+int bd_colsum(const float* rows, size_t M, int N, float* out, float* ws, void* stream);
 /* (imgs, C, HW) -> (imgs, HW, C) when to_nhwc, the reverse otherwise */
 int bd_image_layout(const float* src, float* dst, int imgs, int C, int HW, int to_nhwc, void* stream);
 
