@@ -157,6 +157,7 @@ def main():
     eng.enable_timers(True, every=5 if args.steps >= 10 else 1)
 
     def fence():
+        eng.join()          # everything queued on the engine's streams, incl. optimiser steps it issues one step late
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
