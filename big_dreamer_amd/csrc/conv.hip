@@ -248,6 +248,140 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     if (threadIdx.x == 0) out[c] = red[0];
 }
 
+// ---- patch form: the input patch of a 2-D output tile goes to LDS ONCE ---------------------------------------------
+// The gather form above builds im2col rows: every input element is fetched k*k/4 (F) or Ta*Tb (T) times from L2, and
+// with few output channels (N = 3 / 32 / 64) those fetches, not the MFMAs, are the time (ConvT 32->3: 5 TFLOP/s).
+// Here a workgroup owns RT x 16 output pixels of ONE image (RT grid rows x 16 consecutive grid columns): it copies the
+// (RT*sy + span_y) x (16*sx + span_x) x C input patch to LDS (pixel stride C + 4 floats: the 16 lanes of a fragment read
+// hit distinct bank groups), and the MFMA A fragment of (row tile, K block = (tap, 16 channels)) is one ds_read_b128 at
+//     rt_base[rt] + koff[kb] + (lane & 15) * sx * (C + 4) + 4 * (lane >> 4)
+// -- no im2col image at all.  Needs C % 16 == 0.  Same packed weights, same unit distribution, same epilogue.
+template <int RTC, class Epi>
+__device__ __forceinline__ void patch_segment(const float* __restrict__ Pt, const int* __restrict__ koff,
+                                              const int* __restrict__ rt_base, int rstride, int Kb,
+                                              const float* __restrict__ Wp, const float* __restrict__ bias, int N, int nb,
+                                              int rt0, Epi&& epi) {
+    const int lane = bd_tid() & 63;
+    const int col = nb * 16 + (lane & 15);
+    const float b = (bias != nullptr && col < N) ? bias[col] : 0.f;
+    floatx4 acc[RTC], acc2[RTC];
+    int abase[RTC];
+#pragma unroll
+    for (int r = 0; r < RTC; ++r) {
+        acc[r] = floatx4{b, b, b, b};
+        acc2[r] = floatx4{0.f, 0.f, 0.f, 0.f};
+        abase[r] = rt_base[rt0 + r] + (lane & 15) * rstride + 4 * (lane >> 4);
+    }
+    const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(Wp) + lane + (size_t)nb * Kb * 64;
+    pipelined_k<2>(
+        Kb,
+        [&](int kb) {
+            ConvFrag<RTC> f;
+            f.b = W4[(size_t)kb * 64];
+            const int ko = koff[kb];
+#pragma unroll
+            for (int r = 0; r < RTC; ++r) f.a[r] = *reinterpret_cast<const floatx4*>(Pt + abase[r] + ko);
+            return f;
+        },
+        [&](const ConvFrag<RTC>& f) {
+#pragma unroll
+            for (int r = 0; r < RTC; ++r) {
+                acc[r] = mfma16(f.a[r][0], f.b[0], acc[r]);
+                acc2[r] = mfma16(f.a[r][1], f.b[1], acc2[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < RTC; ++r) {
+                acc[r] = mfma16(f.a[r][2], f.b[2], acc[r]);
+                acc2[r] = mfma16(f.a[r][3], f.b[3], acc2[r]);
+            }
+        });
+#pragma unroll
+    for (int r = 0; r < RTC; ++r) epi(rt0 + r, nb, acc[r] + acc2[r]);
+}
+
+template <int RT>
+__global__ __launch_bounds__(kThreads) void conv_patch_kernel(bd_conv_args a, int tiles_y, int tiles_x, int PH, int PW) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Kb = a.K >> 4, Nb = cdiv(a.N, 16);
+    const int Cp = a.C + 4;
+    float* Pt = smem;                                              // [PH][PW][Cp]
+    int* koff = reinterpret_cast<int*>(Pt + (size_t)PH * PW * Cp); // [Kb]
+    int* rt_base = koff + Kb;                                      // [RT]
+    int* rowoff = rt_base + RT;                                    // [RT*16]
+    const int bx = blockIdx.x;
+    const int img = bx / (tiles_y * tiles_x), trem = bx - img * tiles_y * tiles_x;
+    const int y0 = (trem / tiles_x) * RT, x0 = (trem % tiles_x) * 16;       // tile origin in the row grid
+    const int nseg_b = a.seglen / a.C;                                      // taps along x
+    // input pixel of grid point (y, x), tap (s, b): iy = y*sy + y0_ + s*ss, ix = x*sx + x0_ + b
+    const int ya = (y0 * a.sy + a.y0) + (a.ss < 0 ? -(a.nseg - 1) : 0);     // first patch row in the image
+    const int xa = x0 * a.sx + a.x0;                                        // first patch column
+    // ---- patch -> LDS (zero outside the image) ----
+    const int c4n = a.C >> 2;
+    for (int e = threadIdx.x; e < PH * PW * c4n; e += blockDim.x) {
+        const int c4 = e % c4n, pix = e / c4n;
+        const int px = pix % PW, py = pix / PW;
+        const int iy = ya + py, ix = xa + px;
+        floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
+            v = *reinterpret_cast<const floatx4*>(a.in + (((size_t)img * a.IH + iy) * a.IW + ix) * a.C + 4 * c4);
+        *reinterpret_cast<floatx4*>(Pt + (size_t)pix * Cp + 4 * c4) = v;
+    }
+    const int cbn = a.C >> 4;
+    for (int kb = threadIdx.x; kb < Kb; kb += blockDim.x) {
+        const int cb = kb % cbn, t = kb / cbn;
+        const int b = t % nseg_b, s = t / nseg_b;
+        const int prow = (a.ss < 0 ? (a.nseg - 1 - s) : s);                 // patch row offset of tap s
+        koff[kb] = (prow * PW + b) * Cp + cb * 16;
+    }
+    for (int r = threadIdx.x; r < RT * 16; r += blockDim.x) {
+        const int y = y0 + (r >> 4), x = x0 + (r & 15);
+        rowoff[r] = (y < a.gh && x < a.gw) ? ((img * a.OH + y * a.osy + a.oy0) * a.OW + x * a.osx + a.ox0) * a.ldo : -1;
+        if ((r & 15) == 0) rt_base[r >> 4] = ((r >> 4) * a.sy * PW) * Cp;
+    }
+    lds_barrier();
+    const int nrt = min(RT, a.gh - y0);
+    const int tidc = bd_tid();
+    const int lane = tidc & 63, wave = bd_wave(tidc);
+    const int U = nrt * Nb;
+    const int ub = U / kWaves, urem = U - ub * kWaves;
+    const int u0 = wave * ub + min(wave, urem), u1 = u0 + ub + (wave < urem ? 1 : 0);
+    const int rstride = a.sx * Cp;
+    auto epi = [&](int rt, int nb, floatx4 acc) {
+        const int col = nb * 16 + (lane & 15);
+        if (col >= a.N) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int off = rowoff[rt * 16 + 4 * (lane >> 4) + r];
+            if (off >= 0) a.out[(size_t)off + col] = a.act ? elu(acc[r]) : acc[r];
+        }
+    };
+    int u = u0;
+    while (u < u1) {
+        const int nb = u / nrt, rt0 = u - nb * nrt;
+        const int cnt = min(min(u1 - u, nrt - rt0), 2);
+        if (cnt == 2) patch_segment<2>(Pt, koff, rt_base, rstride, Kb, a.w, a.bias, a.N, nb, rt0, epi);
+        else patch_segment<1>(Pt, koff, rt_base, rstride, Kb, a.w, a.bias, a.N, nb, rt0, epi);
+        u += cnt;
+    }
+}
+
+template <int RT>
+static int launch_patch(const bd_conv_args& a, hipStream_t s) {
+    const int span_y = a.ss < 0 ? a.nseg - 1 : a.nseg - a.sy;              // extra patch rows beyond RT*sy
+    const int nseg_b = a.seglen / a.C;
+    const int span_x = nseg_b - a.sx;
+    const int PH = RT * a.sy + span_y, PW = 16 * a.sx + span_x;
+    const int Kb = a.K >> 4;
+    const size_t lds = ((size_t)PH * PW * (a.C + 4) + Kb + RT + 16 * RT) * sizeof(float);
+    BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_conv_gemm(patch): needs %zu B of LDS", lds);
+    if (lds > 64 * 1024 && allow_big_lds(conv_patch_kernel<RT>)) return -1;
+    const int tiles_y = cdiv(a.gh, RT), tiles_x = cdiv(a.gw, 16);
+    hipLaunchKernelGGL(conv_patch_kernel<RT>, dim3((unsigned)(a.imgs * tiles_y * tiles_x)), dim3(kThreads), lds, s, a, tiles_y,
+                       tiles_x, PH, PW);
+    BD_CHECK_LAUNCH("bd_conv_gemm(patch)");
+    return 0;
+}
+
 template <int RT>
 static int launch_conv(const bd_conv_args& a, hipStream_t s) {
     const int Kb = cdiv(a.K, 16);
@@ -274,6 +408,28 @@ int bd_conv_gemm(const bd_conv_args* a, void* stream) {
                "bd_conv_gemm: image batch too large for 32-bit element offsets");
     BD_REQUIRE(!a->mask || (a->vec4 && (1 << a->cshift) == a->C), "bd_conv_gemm: masked gathers need C a power of two >= 4");
     BD_REQUIRE(!a->vec4 || (a->C % 4 == 0 && a->seglen % 4 == 0), "bd_conv_gemm: vec4 gathers need C, seglen multiples of 4");
+    // patch form (input patch staged in LDS once per 2-D tile): channels a multiple of 16, a grid at least 12 wide (a
+    // row tile is 16 consecutive grid columns) and few enough output channels that the gather traffic matters
+    static const char* patch_env = getenv("BD_CONV_PATCH");
+    const bool patch_ok = !(patch_env && patch_env[0] == '0') && a->C % 16 == 0 && a->gw >= 12 && a->N <= 128 &&
+                          (a->mask ? (a->sy == 1 && a->sx == 1 && a->ss == -1) : (a->sy == 2 && a->sx == 2 && a->ss == 1 && a->x0 == 0 && a->y0 == 0));
+    if (patch_ok) {
+        const int Nb = cdiv(a->N, 16);
+        int rt = 8;                                   // >= 8 (row tile, column block) units, patch <= ~56 KB
+        while (rt > 1 && (rt / 2) * Nb >= 8) rt >>= 1;
+        auto patch_bytes = [&](int r) {
+            const int span_y = a->ss < 0 ? a->nseg - 1 : a->nseg - a->sy, span_x = a->seglen / a->C - a->sx;
+            return (size_t)(r * a->sy + span_y) * (16 * a->sx + span_x) * (a->C + 4) * sizeof(float);
+        };
+        while (rt > 1 && patch_bytes(rt) > 56 * 1024) rt >>= 1;
+        if (rt > a->gh) while (rt > 1 && rt / 2 >= a->gh) rt >>= 1;
+        switch (rt) {
+            case 8: return launch_patch<8>(*a, (hipStream_t)stream);
+            case 4: return launch_patch<4>(*a, (hipStream_t)stream);
+            case 2: return launch_patch<2>(*a, (hipStream_t)stream);
+            default: return launch_patch<1>(*a, (hipStream_t)stream);
+        }
+    }
     // rows per workgroup: as many 16-row tiles as LDS holds (<= 8): the packed weights (K x N) are streamed once per
     // workgroup, 8*RT FLOP per byte.  BD_CONV_RT caps it (tuning).
     const int Kb = cdiv(a->K, 16);

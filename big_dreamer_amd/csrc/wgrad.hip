@@ -6,6 +6,7 @@
 // 64x64 output tile per workgroup, v_mfma_f32_32x32x2_f32 (exact fp32), operands staged through LDS.
 #include "bd_device.h"
 #include "bd_host.h"
+#include <stdint.h>
 #include <stdlib.h>
 
 namespace bd {
@@ -159,6 +160,7 @@ constexpr int kWB = 13;               // 16-blocks per workgroup tile edge
 constexpr int kWLd = 240;             // LDS row stride in floats: 14 blocks + pad, == 16 mod 32
 constexpr int kWRows = 16;            // rows per stage
 constexpr int kWStage = 2 * kWRows * kWLd;   // floats per stage: dpre rows | act rows
+constexpr int kWRing = 3;             // stage buffers (DMA runs two stages ahead)
 constexpr int kWThreads = 512;        // 8 waves: 2 per SIMD, so LDS latency and the stage barrier hide under the other wave
 
 // WN x WK = 16-blocks per wave (the 2 x 4 waves cover up to 2WN x 4WK blocks).  The MFMA loop is branch-free: a wave
@@ -193,10 +195,27 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
     const int ncol = min(nb_cnt * 16, d.N - n0), kcol = min(kb_cnt * 16, d.K - k0);   // real columns of this tile
-    for (int i = threadIdx.x; i < 2 * kWStage; i += kWThreads) wlds[i] = 0.f;
+    for (int i = threadIdx.x; i < kWRing * kWStage; i += kWThreads) wlds[i] = 0.f;
     __syncthreads();
-    if (hb && d.K >= k0 && d.K < k0 + kb_cnt * 16 && threadIdx.x < 2 * kWRows)
+    if (hb && d.K >= k0 && d.K < k0 + kb_cnt * 16 && threadIdx.x < kWRing * kWRows)
         wlds[(threadIdx.x >> 4) * kWStage + kWRows * kWLd + (threadIdx.x & 15) * kWLd + (d.K - k0)] = 1.f;
+    // 16-byte LDS-DMA (one 1 KiB wave-instruction per operand row) wherever rows and columns allow it: the dword form
+    // moves 256 B per instruction and ran the whole kernel at ~1.2 TB/s of operand traffic, not at its MFMA rate.
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool p4 = (ncol & 3) == 0 && (d.ldp & 3) == 0 && al16(d.dpre + n0);
+    const bool gathered = d.g_nseg > 0;
+    const bool a4 = (kcol & 3) == 0 && (k0 & 3) == 0 &&
+                    (gathered ? ((d.g_C & 3) == 0 && (d.g_seglen & 3) == 0 && al16(d.act1))
+                              : ((d.lda1 & 3) == 0 && al16(d.act1) && (d.M1 == d.M || ((d.lda2 & 3) == 0 && al16(d.act2)))));
+    // gathered operand: the window offset of this lane's columns does not depend on the row -- once per workgroup
+    int goff[4] = {0, 0, 0, 0};
+    if (gathered) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int k = k0 + (a4 ? 4 * lane : lane + 64 * cc), sgm = k / d.g_seglen;
+            goff[cc] = sgm * d.g_IW * d.g_C + (k - sgm * d.g_seglen);
+        }
+    }
     auto issue = [&](float* buf, int m0) {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
@@ -205,27 +224,33 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
             float* A = P + kWRows * kWLd;
             if (m < m_end) {
                 const float* prow = d.dpre + (size_t)m * d.ldp + n0;
-                if (d.g_nseg > 0) {       // gathered operand: the k x k x C window of output pixel m (conv.hip, pattern F)
+                if (p4) {
+                    if (4 * lane < ncol) __builtin_amdgcn_global_load_lds((glb_ptr_t)(prow + 4 * lane), (lds_ptr_t)P, 16, 0, 0);
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int c = lane + 64 * cc;
+                        if (c < ncol) __builtin_amdgcn_global_load_lds((glb_ptr_t)(prow + c), (lds_ptr_t)(P + 64 * cc), 4, 0, 0);
+                    }
+                }
+                const float* abase;
+                if (gathered) {       // the k x k x C window of output pixel m (conv.hip, pattern F)
                     const int img = m / (d.g_gh * d.g_gw), rem = m - img * d.g_gh * d.g_gw;
                     const int y = rem / d.g_gw, x = rem - y * d.g_gw;
-                    const float* gbase = d.act1 + (((size_t)img * d.g_IH + 2 * y) * d.g_IW + 2 * x) * d.g_C;
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        const int c = lane + 64 * cc;
-                        if (c < ncol) __builtin_amdgcn_global_load_lds((glb_ptr_t)(prow + c), (lds_ptr_t)(P + 64 * cc), 4, 0, 0);
-                        if (c < kcol) {
-                            const int k = k0 + c, sgm = k / d.g_seglen, off = k - sgm * d.g_seglen;
-                            __builtin_amdgcn_global_load_lds((glb_ptr_t)(gbase + (size_t)sgm * d.g_IW * d.g_C + off),
-                                                             (lds_ptr_t)(A + 64 * cc), 4, 0, 0);
-                        }
-                    }
+                    abase = d.act1 + (((size_t)img * d.g_IH + 2 * y) * d.g_IW + 2 * x) * d.g_C;
                 } else {
-                    const float* arow = (m < d.M1 ? d.act1 + (size_t)m * d.lda1 : d.act2 + (size_t)(m - d.M1) * d.lda2) + k0;
+                    abase = (m < d.M1 ? d.act1 + (size_t)m * d.lda1 : d.act2 + (size_t)(m - d.M1) * d.lda2) + k0;
+                }
+                if (a4) {
+                    if (4 * lane < kcol)
+                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(abase + (gathered ? goff[0] : 4 * lane)), (lds_ptr_t)A, 16, 0, 0);
+                } else {
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) {
                         const int c = lane + 64 * cc;
-                        if (c < ncol) __builtin_amdgcn_global_load_lds((glb_ptr_t)(prow + c), (lds_ptr_t)(P + 64 * cc), 4, 0, 0);
-                        if (c < kcol) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arow + c), (lds_ptr_t)(A + 64 * cc), 4, 0, 0);
+                        if (c < kcol)
+                            __builtin_amdgcn_global_load_lds((glb_ptr_t)(abase + (gathered ? goff[cc] : c)), (lds_ptr_t)(A + 64 * cc), 4,
+                                                             0, 0);
                     }
                 }
             } else {
@@ -241,15 +266,33 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
         }
     };
     const int nst = cdiv(m_end - m_begin, kWRows);
+    // Ring of three stage buffers: the DMA of stage st+2 is issued at the top of stage st, and the end of stage st only
+    // waits for stage st+1 (`vmcnt(n)` with n = this wave's DMA instructions per stage leaves the newest stage in
+    // flight; vmcnt retires in order).  A narrow tile (N = 32 / 64: conv layers) has ~1.5k cycles of MFMAs per
+    // 16-row stage against >= 2.5k cycles of loaded DMA latency: with two buffers every stage waited for its fetch.
+    const int n_dma = 2 * ((p4 ? 1 : cdiv(ncol, 64)) + (a4 ? 1 : cdiv(kcol, 64)));       // 4, 6, ..., 16 per wave and full stage
+    auto wait_keep_newest = [&]() {
+        switch (n_dma) {
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        }
+    };
     __syncthreads();
     issue(wlds, m_begin);
-    __builtin_amdgcn_s_waitcnt(0);     // vmcnt(0) lgkmcnt(0): the DMA has landed
+    if (nst > 1) issue(wlds + kWStage, m_begin + kWRows);
+    __builtin_amdgcn_s_waitcnt(0);     // vmcnt(0) lgkmcnt(0): both have landed
     __syncthreads();
     const int lrow = lane >> 4, lcol = lane & 15;
     for (int st = 0; st < nst; ++st) {
-        const float* buf = wlds + (st & 1) * kWStage;
-        // the other buffer was last read in stage st-1, which every wave has left (barrier below)
-        if (st + 1 < nst) issue(wlds + ((st + 1) & 1) * kWStage, m_begin + (st + 1) * kWRows);
+        const float* buf = wlds + (st % kWRing) * kWStage;
+        // buffer (st+2) % 3 was last read in stage st-1, which every wave has left (barrier below)
+        const bool more = st + 2 < nst;
+        if (more) issue(wlds + ((st + 2) % kWRing) * kWStage, m_begin + (st + 2) * kWRows);
         const float* Pb = buf + lrow * kWLd + my_nb0 * 16 + lcol;
         const float* Ab = buf + kWRows * kWLd + lrow * kWLd + my_kb0 * 16 + lcol;
 #pragma unroll
@@ -264,8 +307,10 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
 #pragma unroll
                 for (int j = 0; j < WK; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
         }
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
+        // stage st+1 must have landed; a full stage st+2 (no tail rows: st + 3 < nst) may stay in flight
+        if (more && st + 3 < nst) wait_keep_newest();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                 // lgkmcnt(0) (tail-row clears) + s_barrier, without draining the DMA
     }
     // lane holds D[n = 4*(lane>>4) + r][k = lane&15] of each 16x16 block
     float* slab = ws + d.ws_off + (size_t)z * d.N * Kext;
@@ -303,10 +348,22 @@ __global__ __launch_bounds__(kWThreads) void wgrad_wide_kernel(const bd_wgrad_de
     const int tn = local / d.tiles_k, tk = local - tn * d.tiles_k;
     const int n0 = tn * nbw * 16, k0 = tk * kbw * 16;
     const int nb_cnt = min(nbw, NB - tn * nbw), kb_cnt = min(kbw, KB - tk * kbw);
-    // narrow outputs (N <= 32: heads; K <= 32: 1..30 input features) keep one block per wave on that side
-    if (nb_cnt <= 2) wgrad_wide_body<1, 4>(d, ws, wlds, hb, Kext, z, n0, k0, nb_cnt, kb_cnt);
-    else if (kb_cnt <= 4) wgrad_wide_body<7, 1>(d, ws, wlds, hb, Kext, z, n0, k0, nb_cnt, kb_cnt);
-    else wgrad_wide_body<7, 4>(d, ws, wlds, hb, Kext, z, n0, k0, nb_cnt, kb_cnt);
+    // The MFMA loop is branch-free over WN x WK blocks per wave, so the instantiation must fit the tile: a 4 x 12-block
+    // tile (N = 64: conv layers) on the 7 x 4 body would issue 28 MFMAs per slice for 6 useful ones.
+    const int hn = (nb_cnt + 1) >> 1, hk = (kb_cnt + 3) >> 2;      // blocks per wave row / wave column
+#define BD_WG_BODY(WN, WK) wgrad_wide_body<WN, WK>(d, ws, wlds, hb, Kext, z, n0, k0, nb_cnt, kb_cnt)
+#define BD_WG_ROW(WN)                      \
+    do {                                   \
+        if (hk <= 1) BD_WG_BODY(WN, 1);    \
+        else if (hk <= 2) BD_WG_BODY(WN, 2); \
+        else BD_WG_BODY(WN, 4);            \
+    } while (0)
+    if (hn <= 1) BD_WG_ROW(1);
+    else if (hn <= 2) BD_WG_ROW(2);
+    else if (hn <= 4) BD_WG_ROW(4);
+    else BD_WG_ROW(7);
+#undef BD_WG_ROW
+#undef BD_WG_BODY
 }
 
 __global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(const bd_wgrad_desc* __restrict__ descs, int n,
@@ -457,7 +514,12 @@ int bd_wgrad_grouped(const bd_wgrad_desc* descs_dev, int n, int total_blocks, in
                "bd_wgrad_grouped: bad arguments");
     if (wgrad_wide()) {
         static_assert(kThreads == 256, "the 64x64-tile wgrad kernels are written for four waves");
-        hipLaunchKernelGGL(wgrad_wide_kernel, dim3(total_blocks), dim3(kWThreads), 2 * kWStage * sizeof(float), (hipStream_t)stream,
+        static bool lds_ok = false;
+        if (!lds_ok) {
+            if (allow_big_lds(wgrad_wide_kernel)) return -1;
+            lds_ok = true;
+        }
+        hipLaunchKernelGGL(wgrad_wide_kernel, dim3(total_blocks), dim3(kWThreads), kWRing * kWStage * sizeof(float), (hipStream_t)stream,
                            descs_dev, n, ws);
     } else {
         hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(total_blocks), dim3(kThreads), 0, (hipStream_t)stream, descs_dev, n, ws);
