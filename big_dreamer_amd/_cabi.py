@@ -105,7 +105,7 @@ class ConvArgs(C.Structure):
                 ("nseg", I32), ("seglen", I32), ("C", I32), ("IH", I32), ("IW", I32), ("sy", I32), ("y0", I32),
                 ("ss", I32), ("sx", I32), ("x0", I32), ("mask", I32), ("cshift", I32), ("vec4", I32),
                 ("OH", I32), ("OW", I32), ("osy", I32), ("oy0", I32), ("osx", I32), ("ox0", I32), ("ldo", I32),
-                ("act", I32)]
+                ("act", I32), ("fuse_cq", I32)]
 
 
 # every symbol include/bigdreamer_hip.h declares, with its signature
@@ -145,6 +145,7 @@ _SIGS = {
     "bd_reduce_ws_floats": (C.c_size_t, []),
     "bd_conv_gemm": (I32, [C.POINTER(ConvArgs), P]),
     "bd_conv_pack_class": (I32, [P, P, I32, I32, I32, I32, I32, I32, I32, P]),
+    "bd_conv_pack_fused": (I32, [P, P, I32, I32, I32, P]),
     "bd_elu_backward": (I32, [P, P, C.c_size_t, P]),
     "bd_image_layout": (I32, [P, P, I32, I32, I32, I32, P]),
     "bd_colsum_ws_floats": (C.c_size_t, [I32]),

@@ -73,6 +73,33 @@ def pattern_t(inp: torch.Tensor, out: torch.Tensor, w_classes: List[torch.Tensor
             cabi.check(lib.bd_conv_gemm(C.byref(a), cabi.stream()))
 
 
+def pattern_t_fused(inp: torch.Tensor, out: torch.Tensor, w_fused: torch.Tensor, bias, imgs: int, IH: int, IW: int, Cin: int,
+                    k: int, N: int, OH: int, OW: int, act: int) -> None:
+    """pattern_t with the four parity classes in ONE launch: they read the same T x T window (T = (k+1)//2), so their
+    weights are the columns of one matrix (fused_pack) and the window is gathered once instead of four times."""
+    assert Cin % 4 == 0 and Cin & (Cin - 1) == 0, "T pattern: channel count must be a power of two >= 4"
+    T = (k + 1) // 2
+    a = cabi.ConvArgs()
+    a.in_, a.out, a.w, a.bias = ptr(inp), ptr(out), ptr(w_fused), ptr(bias)
+    a.imgs, a.gh, a.gw, a.N, a.K = imgs, (OH + 1) // 2, (OW + 1) // 2, 4 * N, T * T * Cin
+    a.nseg, a.seglen, a.C, a.IH, a.IW = T, T * Cin, Cin, IH, IW
+    a.sy, a.y0, a.ss, a.sx, a.x0, a.mask = 1, 0, -1, 1, -(T - 1), 1
+    a.vec4, a.cshift = 1, _log2(Cin)
+    a.OH, a.OW, a.osy, a.oy0, a.osx, a.ox0, a.ldo = OH, OW, 2, 0, 2, 0, N
+    a.act, a.fuse_cq = act, N
+    cabi.check(lib.bd_conv_gemm(C.byref(a), cabi.stream()))
+
+
+def fused_pack_floats(Couter: int, Cinner: int, k: int) -> int:
+    T = (k + 1) // 2
+    return cabi.packed_floats(4 * Cinner, T * T * Couter)
+
+
+def pack_fused(stored: torch.Tensor, dst: torch.Tensor, Couter: int, Cinner: int, k: int) -> None:
+    """stored: (Couter, k, k, Cinner) contiguous -> the fused four-class pack of pattern_t_fused."""
+    cabi.check(lib.bd_conv_pack_fused(ptr(stored), ptr(dst), Couter, Cinner, k, cabi.stream()))
+
+
 def class_pack_floats(Couter: int, Cinner: int, k: int) -> List[int]:
     return [cabi.packed_floats(Cinner, taps(k, py) * taps(k, px) * Couter) for py in range(2) for px in range(2)]
 

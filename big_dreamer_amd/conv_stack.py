@@ -40,10 +40,10 @@ class ConvStacks:
         z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
         # ---- packed weight copies (rebuilt by pack() after every model optimiser step) ----
         self.pk_enc_f = [z(cabi.packed_floats(co, k * k * ci)) for ci, co, k in ENC]
-        self.pk_enc_t = [None] + [[z(n) for n in conv.class_pack_floats(co, ci, k)] for ci, co, k in ENC[1:]]
+        self.pk_enc_t = [None] + [z(conv.fused_pack_floats(co, ci, k)) for ci, co, k in ENC[1:]]     # four classes fused
         self.pk_dec1 = z(cabi.packed_floats(25 * 128, d.E))                       # (ky, kx, co) x ci
         self.bias_dec1 = z(25 * 128)
-        self.pk_dec_t = [[z(n) for n in conv.class_pack_floats(ci, co, k)] for ci, co, k in DEC]
+        self.pk_dec_t = [z(conv.fused_pack_floats(ci, co, k)) for ci, co, k in DEC]
         self.pk_dec_f = [z(cabi.packed_floats(ci, k * k * co)) for ci, co, k in DEC]
         self.pk_dec0 = z(cabi.packed_floats(d.E, d.Be + d.S))
         self.pk_dec0_t = z(cabi.packed_floats(d.E, d.Be + d.S))
@@ -86,9 +86,9 @@ class ConvStacks:
         cabi.check(lib.bd_pack_weights(raw.data_ptr(), n, cabi.stream()))
         for i, (ci, co, k) in enumerate(ENC):
             if i > 0:          # dgrad of conv i (pattern T): stored (co, ky, kx, ci), outer = co
-                conv.pack_classes(e.Ws("encoder", f"model.{2 * i}.weight"), self.pk_enc_t[i], co, ci, k)
+                conv.pack_fused(e.Ws("encoder", f"model.{2 * i}.weight"), self.pk_enc_t[i], co, ci, k)
         for j, (ci, co, k) in enumerate(DEC):      # forward of transposed conv j: stored (ci, ky, kx, co), outer = ci
-            conv.pack_classes(e.Ws("observation_model", f"decoder.{DEC_IDX[j]}.weight"), self.pk_dec_t[j], ci, co, k)
+            conv.pack_fused(e.Ws("observation_model", f"decoder.{DEC_IDX[j]}.weight"), self.pk_dec_t[j], ci, co, k)
         # the 1x1 -> 5x5 layer's bias, once per output pixel
         self.bias_dec1.view(25, 128).copy_(e.W("observation_model", "decoder.2.bias").unsqueeze(0).expand(25, 128))
 
@@ -129,8 +129,8 @@ class ConvStacks:
         for j, (ci, co, k) in enumerate(DEC):
             sz = DEC_SIZES[j + 1]
             y = e.buf(tag + f"cv_d{j + 2}", M, sz, sz, co)
-            conv.pattern_t(self.acts_dec[-1], y, self.pk_dec_t[j], e.W("observation_model", f"decoder.{DEC_IDX[j]}.bias"), M,
-                           DEC_SIZES[j], DEC_SIZES[j], ci, k, co, sz, sz, cabi.ACT_ELU if j < 2 else cabi.ACT_NONE)
+            conv.pattern_t_fused(self.acts_dec[-1], y, self.pk_dec_t[j], e.W("observation_model", f"decoder.{DEC_IDX[j]}.bias"),
+                                 M, DEC_SIZES[j], DEC_SIZES[j], ci, k, co, sz, sz, cabi.ACT_ELU if j < 2 else cabi.ACT_NONE)
             self.acts_dec.append(y)
         return self.acts_dec[-1]
 
@@ -196,5 +196,5 @@ class ConvStacks:
                    G(f"model.{2 * i}.bias"), gather=(k, k * ci, osz, osz, isz, isz, ci))
             if i > 0:
                 gi = e.buf(f"cv_ga{i}", M, isz, isz, ci)
-                conv.pattern_t(g, gi, self.pk_enc_t[i], None, M, osz, osz, co, k, ci, isz, isz, cabi.ACT_NONE)
+                conv.pattern_t_fused(g, gi, self.pk_enc_t[i], None, M, osz, osz, co, k, ci, isz, isz, cabi.ACT_NONE)
                 g = gi

@@ -31,10 +31,10 @@ struct ConvFrag {
 // One segment: column block nb, row tiles rt0 .. rt0+RTC-1 of the LDS tile X[rt][Kb] (fragment order).
 template <int RTC, class Epi>
 __device__ __forceinline__ void conv_segment(const float* __restrict__ X, int Kb, const float* __restrict__ Wp,
-                                             const float* __restrict__ bias, int N, int nb, int rt0, Epi&& epi) {
+                                             const float* __restrict__ bias, int N, int bmod, int nb, int rt0, Epi&& epi) {
     const int lane = bd_tid() & 63;
     const int col = nb * 16 + (lane & 15);
-    const float b = (bias != nullptr && col < N) ? bias[col] : 0.f;
+    const float b = (bias != nullptr && col < N) ? bias[bmod > 0 ? col % bmod : col] : 0.f;
     floatx4 acc[RTC], acc2[RTC];      // two chains per row tile: a lone dependent chain pays 40 cycles per 32-cycle MFMA
 #pragma unroll
     for (int r = 0; r < RTC; ++r) {
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(bd_conv_args a) {
     const int Kb = cdiv(a.K, 16), Nb = cdiv(a.N, 16);
     float* X = smem;                                            // [RT][Kb] fragment tiles
     int* rowoff = reinterpret_cast<int*>(smem + (size_t)RT * Kb * kFragFloats);   // output element offset per row, -1: none
+    int* rowflag = rowoff + 16 * RT;
     const int M = a.imgs * a.gh * a.gw;
     const int row0 = blockIdx.x * 16 * RT;
     constexpr int kRows = 16 * RT;
@@ -91,8 +92,10 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(bd_conv_args a) {
             y = rem / a.gw;
             x = rem - y * a.gw;
         }
-        if (j0 == 0)
+        if (j0 == 0) {
             rowoff[r] = rok ? ((img * a.OH + y * a.osy + a.oy0) * a.OW + x * a.osx + a.ox0) * a.ldo : -1;
+            rowflag[r] = (2 * y + 1 < a.OH ? 1 : 0) | (2 * x + 1 < a.OW ? 2 : 0);     // fused classes: odd row / column exist
+        }
         const int iy0 = y * a.sy + a.y0, ix0 = x * a.sx + a.x0;
         const float* __restrict__ base = a.in + ((size_t)img * a.IH * a.IW) * a.C;
         float* __restrict__ Xr = X + (size_t)(r >> 4) * Kb * kFragFloats;
@@ -132,20 +135,27 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(bd_conv_args a) {
     auto epi = [&](int rt, int nb, floatx4 acc) {
         const int col = nb * 16 + (lane & 15);
         if (col >= a.N) return;
+        int coff = col, need = 0;
+        if (a.fuse_cq > 0) {            // column = class * Cq + channel: pixel (2y + py, 2x + px)
+            const int cls = col / a.fuse_cq, py = cls >> 1, px = cls & 1;
+            coff = (py * a.OW + px) * a.ldo + (col - cls * a.fuse_cq);
+            need = py | (px << 1);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int off = rowoff[rt * 16 + 4 * (lane >> 4) + r];
-            if (off >= 0) a.out[(size_t)off + col] = a.act ? elu(acc[r]) : acc[r];
+            const int row = rt * 16 + 4 * (lane >> 4) + r;
+            const int off = rowoff[row];
+            if (off >= 0 && (rowflag[row] & need) == need) a.out[(size_t)off + coff] = a.act ? elu(acc[r]) : acc[r];
         }
     };
     int u = u0;
     while (u < u1) {
         const int nb = u / nrt, rt0 = u - nb * nrt;
         const int cnt = min(min(u1 - u, nrt - rt0), 4);
-        if (cnt == 4) conv_segment<4>(X, Kb, a.w, a.bias, a.N, nb, rt0, epi);
-        else if (cnt == 3) conv_segment<3>(X, Kb, a.w, a.bias, a.N, nb, rt0, epi);
-        else if (cnt == 2) conv_segment<2>(X, Kb, a.w, a.bias, a.N, nb, rt0, epi);
-        else conv_segment<1>(X, Kb, a.w, a.bias, a.N, nb, rt0, epi);
+        if (cnt == 4) conv_segment<4>(X, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi);
+        else if (cnt == 3) conv_segment<3>(X, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi);
+        else if (cnt == 2) conv_segment<2>(X, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi);
+        else conv_segment<1>(X, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi);
         u += cnt;
     }
 }
@@ -174,6 +184,38 @@ __global__ __launch_bounds__(256) void conv_pack_class_kernel(const float* __res
                 const int bp = t % Tb, ta = t / Tb;
                 const int ky = py + 2 * ta, kx = px + 2 * (Tb - 1 - bp);
                 xv = src[(((size_t)c * ksz + ky) * ksz + kx) * Cinner + n];
+            }
+            v[i] = xv;
+        }
+        d4[e] = v;
+    }
+}
+
+// All four parity classes in one weight matrix (bd_conv_args.fuse_cq): they read the same T x T input window, T = (ksz+1)/2:
+//   dst[n = cls*Cinner + c][k = (a, b', outer)] = src[outer][py + 2a][px + 2(T-1-b')][c], 0 where ky or kx >= ksz
+__global__ __launch_bounds__(256) void conv_pack_fused_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                              int Couter, int Cinner, int ksz) {
+    const int T = (ksz + 1) >> 1;
+    const int K = T * T * Couter, N = 4 * Cinner;
+    const int Nb = (N + 15) >> 4, Kb = (K + 15) >> 4;
+    const int total = Nb * Kb * 64;
+    floatx4* __restrict__ d4 = reinterpret_cast<floatx4*>(dst);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int lane = e & 63, blk = e >> 6;
+        const int nb = blk / Kb, kb = blk - nb * Kb;
+        const int n = nb * 16 + (lane & 15);
+        const int k0 = kb * 16 + 4 * (lane >> 4);
+        const int cls = n / Cinner, c = n - cls * Cinner, py = cls >> 1, px = cls & 1;
+        floatx4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + i;
+            float xv = 0.f;
+            if (n < N && k < K) {
+                const int co = k % Couter, t = k / Couter;
+                const int bp = t % T, ta = t / T;
+                const int ky = py + 2 * ta, kx = px + 2 * (T - 1 - bp);
+                if (ky < ksz && kx < ksz) xv = src[(((size_t)co * ksz + ky) * ksz + kx) * Cinner + c];
             }
             v[i] = xv;
         }
@@ -259,11 +301,11 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 template <int RTC, class Epi>
 __device__ __forceinline__ void patch_segment(const float* __restrict__ Pt, const int* __restrict__ koff,
                                               const int* __restrict__ rt_base, int rstride, int Kb,
-                                              const float* __restrict__ Wp, const float* __restrict__ bias, int N, int nb,
-                                              int rt0, Epi&& epi) {
+                                              const float* __restrict__ Wp, const float* __restrict__ bias, int N, int bmod,
+                                              int nb, int rt0, Epi&& epi) {
     const int lane = bd_tid() & 63;
     const int col = nb * 16 + (lane & 15);
-    const float b = (bias != nullptr && col < N) ? bias[col] : 0.f;
+    const float b = (bias != nullptr && col < N) ? bias[bmod > 0 ? col % bmod : col] : 0.f;
     floatx4 acc[RTC], acc2[RTC];
     int abase[RTC];
 #pragma unroll
@@ -308,6 +350,7 @@ __global__ __launch_bounds__(kThreads) void conv_patch_kernel(bd_conv_args a, in
     int* koff = reinterpret_cast<int*>(Pt + (size_t)PH * PW * Cp); // [Kb]
     int* rt_base = koff + Kb;                                      // [RT]
     int* rowoff = rt_base + RT;                                    // [RT*16]
+    int* rowflag = rowoff + 16 * RT;                               // [RT*16]
     const int bx = blockIdx.x;
     const int img = bx / (tiles_y * tiles_x), trem = bx - img * tiles_y * tiles_x;
     const int y0 = (trem / tiles_x) * RT, x0 = (trem % tiles_x) * 16;       // tile origin in the row grid
@@ -336,6 +379,7 @@ __global__ __launch_bounds__(kThreads) void conv_patch_kernel(bd_conv_args a, in
     for (int r = threadIdx.x; r < RT * 16; r += blockDim.x) {
         const int y = y0 + (r >> 4), x = x0 + (r & 15);
         rowoff[r] = (y < a.gh && x < a.gw) ? ((img * a.OH + y * a.osy + a.oy0) * a.OW + x * a.osx + a.ox0) * a.ldo : -1;
+        rowflag[r] = (2 * y + 1 < a.OH ? 1 : 0) | (2 * x + 1 < a.OW ? 2 : 0);
         if ((r & 15) == 0) rt_base[r >> 4] = ((r >> 4) * a.sy * PW) * Cp;
     }
     lds_barrier();
@@ -349,18 +393,25 @@ __global__ __launch_bounds__(kThreads) void conv_patch_kernel(bd_conv_args a, in
     auto epi = [&](int rt, int nb, floatx4 acc) {
         const int col = nb * 16 + (lane & 15);
         if (col >= a.N) return;
+        int coff = col, need = 0;
+        if (a.fuse_cq > 0) {            // column = class * Cq + channel: pixel (2y + py, 2x + px)
+            const int cls = col / a.fuse_cq, py = cls >> 1, px = cls & 1;
+            coff = (py * a.OW + px) * a.ldo + (col - cls * a.fuse_cq);
+            need = py | (px << 1);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int off = rowoff[rt * 16 + 4 * (lane >> 4) + r];
-            if (off >= 0) a.out[(size_t)off + col] = a.act ? elu(acc[r]) : acc[r];
+            const int row = rt * 16 + 4 * (lane >> 4) + r;
+            const int off = rowoff[row];
+            if (off >= 0 && (rowflag[row] & need) == need) a.out[(size_t)off + coff] = a.act ? elu(acc[r]) : acc[r];
         }
     };
     int u = u0;
     while (u < u1) {
         const int nb = u / nrt, rt0 = u - nb * nrt;
         const int cnt = min(min(u1 - u, nrt - rt0), 2);
-        if (cnt == 2) patch_segment<2>(Pt, koff, rt_base, rstride, Kb, a.w, a.bias, a.N, nb, rt0, epi);
-        else patch_segment<1>(Pt, koff, rt_base, rstride, Kb, a.w, a.bias, a.N, nb, rt0, epi);
+        if (cnt == 2) patch_segment<2>(Pt, koff, rt_base, rstride, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi);
+        else patch_segment<1>(Pt, koff, rt_base, rstride, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi);
         u += cnt;
     }
 }
@@ -372,7 +423,7 @@ static int launch_patch(const bd_conv_args& a, hipStream_t s) {
     const int span_x = nseg_b - a.sx;
     const int PH = RT * a.sy + span_y, PW = 16 * a.sx + span_x;
     const int Kb = a.K >> 4;
-    const size_t lds = ((size_t)PH * PW * (a.C + 4) + Kb + RT + 16 * RT) * sizeof(float);
+    const size_t lds = ((size_t)PH * PW * (a.C + 4) + Kb + RT + 32 * RT) * sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_conv_gemm(patch): needs %zu B of LDS", lds);
     if (lds > 64 * 1024 && allow_big_lds(conv_patch_kernel<RT>)) return -1;
     const int tiles_y = cdiv(a.gh, RT), tiles_x = cdiv(a.gw, 16);
@@ -385,7 +436,7 @@ static int launch_patch(const bd_conv_args& a, hipStream_t s) {
 template <int RT>
 static int launch_conv(const bd_conv_args& a, hipStream_t s) {
     const int Kb = cdiv(a.K, 16);
-    const size_t lds = ((size_t)RT * Kb * kFragFloats + 16 * RT) * sizeof(float);
+    const size_t lds = ((size_t)RT * Kb * kFragFloats + 32 * RT) * sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_conv_gemm: K=%d needs %zu B of LDS at %d rows per workgroup", a.K, lds, 16 * RT);
     if (lds > 64 * 1024 && allow_big_lds(conv_gemm_kernel<RT>)) return -1;
     const long M = (long)a.imgs * a.gh * a.gw;
@@ -407,6 +458,8 @@ int bd_conv_gemm(const bd_conv_args* a, void* stream) {
     BD_REQUIRE((long)a->imgs * a->gh * a->gw < (1L << 31) && (long)a->imgs * a->OH * a->OW * a->ldo < (1L << 31),
                "bd_conv_gemm: image batch too large for 32-bit element offsets");
     BD_REQUIRE(!a->mask || (a->vec4 && (1 << a->cshift) == a->C), "bd_conv_gemm: masked gathers need C a power of two >= 4");
+    BD_REQUIRE(a->fuse_cq == 0 || (a->mask && a->N == 4 * a->fuse_cq && a->osy == 2 && a->osx == 2 && a->oy0 == 0 && a->ox0 == 0),
+               "bd_conv_gemm: fused classes need pattern T with N = 4*fuse_cq");
     BD_REQUIRE(!a->vec4 || (a->C % 4 == 0 && a->seglen % 4 == 0), "bd_conv_gemm: vec4 gathers need C, seglen multiples of 4");
     // patch form (input patch staged in LDS once per 2-D tile): channels a multiple of 16, a grid at least 12 wide (a
     // row tile is 16 consecutive grid columns) and few enough output channels that the gather traffic matters
@@ -436,7 +489,7 @@ int bd_conv_gemm(const bd_conv_args* a, void* stream) {
     static const char* cap_env = getenv("BD_CONV_RT");
     int rt = 8;
     if (cap_env && atoi(cap_env) >= 1 && atoi(cap_env) < 8) rt = atoi(cap_env) >= 4 ? 4 : (atoi(cap_env) >= 2 ? 2 : 1);
-    while (rt > 1 && ((size_t)rt * Kb * kFragFloats + 16 * rt) * sizeof(float) > 150 * 1024) rt >>= 1;
+    while (rt > 1 && ((size_t)rt * Kb * kFragFloats + 32 * rt) * sizeof(float) > 150 * 1024) rt >>= 1;
     switch (rt) {
         case 8: return launch_conv<8>(*a, (hipStream_t)stream);
         case 4: return launch_conv<4>(*a, (hipStream_t)stream);
@@ -452,6 +505,13 @@ int bd_conv_pack_class(const float* src, float* dst, int Couter, int Cinner, int
     hipLaunchKernelGGL(conv_pack_class_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, src, dst, Couter, Cinner, ksz, py,
                        px, Ta, Tb);
     BD_CHECK_LAUNCH("bd_conv_pack_class");
+    return 0;
+}
+
+int bd_conv_pack_fused(const float* src, float* dst, int Couter, int Cinner, int ksz, void* stream) {
+    BD_REQUIRE(src && dst && Couter > 0 && Cinner > 0 && ksz > 0, "bd_conv_pack_fused: bad arguments");
+    hipLaunchKernelGGL(conv_pack_fused_kernel, dim3(128), dim3(256), 0, (hipStream_t)stream, src, dst, Couter, Cinner, ksz);
+    BD_CHECK_LAUNCH("bd_conv_pack_fused");
     return 0;
 }
 

@@ -139,11 +139,17 @@ typedef struct {
     int nseg, seglen, C, IH, IW, sy, y0, ss, sx, x0, mask, cshift, vec4;
     int OH, OW, osy, oy0, osx, ox0, ldo;
     int act;              /* BD_ACT_*                                                                      */
+    int fuse_cq;          /* pattern T with its four parity classes fused: N = 4*fuse_cq columns, column n = cls*fuse_cq
+                           * + c goes to pixel (2y + (cls>>1), 2x + (cls&1)), channel c (osy = osx = 2, oy0 = ox0 = 0;
+                           * gh x gw = the class-(0,0) grid; bias indexed by c); 0 = one class per call                */
 } bd_conv_args;
 int bd_conv_gemm(const bd_conv_args* a, void* stream);
 /* dst (packed) [n = inner][k = (a, b', outer)] = src[outer][py+2a][px+2(Tb-1-b')][inner], src stored (outer, ky, kx, inner) */
 int bd_conv_pack_class(const float* src, float* dst, int Couter, int Cinner, int ksz, int py, int px, int Ta, int Tb,
                        void* stream);
+/* all four parity classes at once (bd_conv_args.fuse_cq): dst [n = cls*Cinner + c][k = (a, b', outer)], T x T taps with
+ * T = (ksz+1)/2, zero where the tap falls outside the kernel (odd ksz, parity 1) */
+int bd_conv_pack_fused(const float* src, float* dst, int Couter, int Cinner, int ksz, void* stream);
 /* g *= ELU'(y) in place from saved ELU outputs (n a multiple of 4) */
 int bd_elu_backward(float* g, const float* y, size_t n, void* stream);
 /* out[n] = sum_m rows[m][n] of an [M x N] row-major matrix, N <= 256 (bias gradient of a transposed-conv layer);

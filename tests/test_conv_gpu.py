@@ -52,8 +52,15 @@ def test_pattern_t_matches_conv_transpose2d(Cin, Cout, k, size):
     conv.pack_classes(stored, packs, Cin, Cout, k)
     OH = conv.convT_out(size, k)
     out = torch.full((imgs, OH, OH, Cout), float("nan"), device="cuda")       # every pixel must be written
-    conv.pattern_t(conv.to_nhwc(x), out, packs, b, imgs, size, size, Cin, k, Cout, OH, OH, cabi.ACT_NONE)
+    xs = conv.to_nhwc(x)
+    conv.pattern_t(xs, out, packs, b, imgs, size, size, Cin, k, Cout, OH, OH, cabi.ACT_NONE)
     _close(conv.to_nchw(out), want)
+    # the four classes fused into one launch
+    fused = torch.zeros(conv.fused_pack_floats(Cin, Cout, k), device="cuda")
+    conv.pack_fused(stored, fused, Cin, Cout, k)
+    out2 = torch.full((imgs, OH, OH, Cout), float("nan"), device="cuda")
+    conv.pattern_t_fused(xs, out2, fused, b, imgs, size, size, Cin, k, Cout, OH, OH, cabi.ACT_NONE)
+    _close(conv.to_nchw(out2), want)
 
 
 @pytest.mark.parametrize("Cin,Cout,k,size", ENC[1:])
@@ -71,8 +78,14 @@ def test_conv2d_dgrad_is_pattern_t_and_convT_dgrad_is_pattern_f(Cin, Cout, k, si
     conv.pack_classes(stored, packs, Cout, Cin, k)
     OH = conv.conv_out(size, k)
     out = torch.full((imgs, size, size, Cin), float("nan"), device="cuda")
-    conv.pattern_t(conv.to_nhwc(gy), out, packs, None, imgs, OH, OH, Cout, k, Cin, size, size, cabi.ACT_NONE)
+    gys = conv.to_nhwc(gy)
+    conv.pattern_t(gys, out, packs, None, imgs, OH, OH, Cout, k, Cin, size, size, cabi.ACT_NONE)
     _close(conv.to_nchw(out), gx)
+    fused = torch.zeros(conv.fused_pack_floats(Cout, Cin, k), device="cuda")
+    conv.pack_fused(stored, fused, Cout, Cin, k)
+    out2 = torch.full((imgs, size, size, Cin), float("nan"), device="cuda")
+    conv.pattern_t_fused(gys, out2, fused, None, imgs, OH, OH, Cout, k, Cin, size, size, cabi.ACT_NONE)
+    _close(conv.to_nchw(out2), gx)
     # transposed convolution with the same tensor as its (ci=Cout, co=Cin) weight: dgrad = strided conv of the gradient
     xt = torch.randn(imgs, Cout, OH, OH, device="cuda", generator=g, requires_grad=True)
     yt = Fnn.conv_transpose2d(xt, w, None, stride=2)                  # w viewed as (ci=Cout, co=Cin, k, k)
