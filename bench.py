@@ -194,7 +194,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "schedule": ("cross-step pipeline on 3 HIP streams (dynamics learning k+1 | behaviour learning k | critic k)"
                          if eng.pipeline else "serial, one stream"),
-            "config": {"workload": ("BASELINE.json configs[2]: 64x64 pixel-obs Dreamer train_step (conv stacks on MIOpen), "
+            "config": {"workload": ("BASELINE.json configs[2]: 64x64 pixel-obs Dreamer train_step (conv stacks on "
+                                    + ("this library's gather-GEMM kernels" if eng.conv_hip else "MIOpen") + "), "
                                     "belief=200 state=30 hidden=200 embedding=1024 action=17, batch=50/GPU chunk=50 H=15")
                        if args.pixel else
                        ("BASELINE.json configs[1]: state-obs Dreamer train_step, belief=200 state=30 "

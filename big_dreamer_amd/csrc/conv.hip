@@ -453,7 +453,7 @@ using namespace bd;
 int bd_conv_gemm(const bd_conv_args* a, void* stream) {
     BD_REQUIRE(a && a->in && a->out && a->w && a->imgs > 0 && a->gh > 0 && a->gw > 0 && a->N > 0 && a->K > 0 &&
                    a->nseg > 0 && a->seglen > 0 && a->nseg * a->seglen == a->K && a->C > 0 && a->IH > 0 && a->IW > 0 &&
-                   a->OH > 0 && a->OW > 0 && a->ldo >= a->N,
+                   a->OH > 0 && a->OW > 0 && a->ldo >= (a->fuse_cq > 0 ? a->fuse_cq : a->N),
                "bd_conv_gemm: bad arguments");
     BD_REQUIRE((long)a->imgs * a->gh * a->gw < (1L << 31) && (long)a->imgs * a->OH * a->OW * a->ldo < (1L << 31),
                "bd_conv_gemm: image batch too large for 32-bit element offsets");

@@ -140,10 +140,10 @@ class DreamerEngine:
                                process_group, phase_groups)
         d = dims
         shapes = param_shapes(d)
-        # pixel mode: BD_CONV=hip runs the conv stacks on this library's gather-GEMM kernels (csrc/conv.hip,
-        # conv_stack.py; parity-green, 25.8 ms/step at configs[2]); the default keeps them on MIOpen through torch
-        # autograd, the measured incumbent (17.9 ms/step) -- see DESIGN.md section 5, row R11
-        self.conv_hip = self.pixel and os.environ.get("BD_CONV", "miopen") == "hip"
+        # pixel mode: the conv stacks run on this library's gather-GEMM kernels (csrc/conv.hip, conv_stack.py;
+        # 17.9 ms/step at configs[2], 18.9 serial); BD_CONV=miopen keeps them on MIOpen through torch autograd, the
+        # measured incumbent (17.9 ms/step, 20.0 serial) -- see DESIGN.md section 5, row R11
+        self.conv_hip = self.pixel and os.environ.get("BD_CONV", "hip") != "miopen"
         self.groups = {
             "model": ParamGroup([(m, n, s) for m in MODEL_MODULES for n, s in shapes[m]], self.dev,
                                 conv_storage=self.conv_hip),

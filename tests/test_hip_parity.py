@@ -97,13 +97,13 @@ def test_forward_pieces_vs_oracle(name):
                                           ("config1", True), ("config2", True), ("small", False),
                                           ("tiny_freenats0", False), ("config2", False),
                                           ("tiny_pixel", True), ("tiny_pixel_lin", True),
-                                          ("tiny_pixel", "hipconv"), ("tiny_pixel_lin", "hipconv")])
+                                          ("tiny_pixel", "miopen"), ("tiny_pixel_lin", "miopen")])
 def test_train_steps_vs_oracle_and_golden(name, cluster, monkeypatch):
     """Two whole train steps: losses, clipped gradients, gradient norms, post-Adam weights -- with the observe
     scan run by the multi-CU cluster kernels (default) and by the single-workgroup kernels."""
     from oracle import dreamer_oracle as O
-    if cluster == "hipconv":        # the pixel conv stacks on this library's gather-GEMM kernels instead of MIOpen
-        monkeypatch.setenv("BD_CONV", "hip")
+    if cluster == "miopen":         # the pixel conv stacks on MIOpen through torch autograd instead of conv.hip
+        monkeypatch.setenv("BD_CONV", "miopen")
         cluster = True
     d, seed, hp, full, g, P, batch, noise, eng = _setup(name, cluster)
     if d.pixel:
