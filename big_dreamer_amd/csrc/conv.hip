@@ -101,26 +101,37 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(bd_conv_args a) {
         float* __restrict__ Xr = X + (size_t)(r >> 4) * Kb * kFragFloats;
         const int rr = r & 15;
         const int Kp = Kb * 16;
+        // (segment, offset) of k advance incrementally: one division per thread, not one per element
         if (a.vec4) {      // C % 4 == 0: segments are 16-byte aligned runs
+            int s = (4 * j0) / a.seglen, off = 4 * j0 - s * a.seglen;
             for (int k = 4 * j0; k < Kp; k += 4 * kTpr) {
                 floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
                 if (rok && k < a.K) {
-                    const int s = k / a.seglen, off = k - s * a.seglen;
                     const int iy = iy0 + s * a.ss, ix = ix0 + (off >> a.cshift);
                     if (!a.mask || (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW))
                         v = *reinterpret_cast<const floatx4*>(base + ((size_t)iy * a.IW + ix0) * a.C + off);
                 }
                 *reinterpret_cast<floatx4*>(Xr + frag_idx(rr, k)) = v;
+                off += 4 * kTpr;
+                while (off >= a.seglen) {
+                    off -= a.seglen;
+                    ++s;
+                }
             }
         } else {
+            int s = j0 / a.seglen, off = j0 - s * a.seglen;
             for (int k = j0; k < Kp; k += kTpr) {
                 float v = 0.f;
                 if (rok && k < a.K) {
-                    const int s = k / a.seglen, off = k - s * a.seglen;
                     const int iy = iy0 + s * a.ss;
                     v = base[((size_t)iy * a.IW + ix0) * a.C + off];       // (unmasked pattern only: host checks)
                 }
                 Xr[frag_idx(rr, k)] = v;
+                off += kTpr;
+                while (off >= a.seglen) {
+                    off -= a.seglen;
+                    ++s;
+                }
             }
         }
     }
