@@ -159,8 +159,10 @@ class DreamerEngine:
         self.red_ws = torch.zeros(int(lib.bd_reduce_ws_floats()), dtype=torch.float32, device=self.dev)
         self._wgrad_ws = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self._wgrad_ws_side = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self._wgrad_ws_early = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.red_ws_side = torch.zeros(int(lib.bd_reduce_ws_floats()), dtype=torch.float32, device=self.dev)
-        self._wbatch = {"model": WgradBatch(self, "model"), "actor": WgradBatch(self, "actor", "_wgrad_ws_bh"),
+        self._wbatch = {"model": WgradBatch(self, "model"), "model_early": WgradBatch(self, "model_early", "_wgrad_ws_early"),
+                        "actor": WgradBatch(self, "actor", "_wgrad_ws_bh"),
                         "critic": WgradBatch(self, "critic", "_wgrad_ws_side")}
         # The critic update only needs the imagined features and the lambda-returns, and the actor's backward pass uses
         # the critic TARGET: the two are independent, so the critic phase runs on a second HIP stream underneath the
@@ -169,6 +171,7 @@ class DreamerEngine:
         # by default (BD_OVERLAP_CRITIC=1 enables it; parity-tested either way).
         self.overlap_critic = os.environ.get("BD_OVERLAP_CRITIC", "0") == "1"
         self._side = torch.cuda.Stream(device=self.dev)
+        self._s_early = torch.cuda.Stream(device=self.dev)      # pixel mode: decoder weight gradients under the observe scan
         # Cross-step software pipeline (on unless BD_PIPELINE=0).  Dynamics learning of step k+1 reads only the world
         # model that step k's model optimiser wrote, never what step k's behaviour learning (imagination, actor,
         # critic) produces, while behaviour learning k needs the world model k and the posteriors k.  So the two
@@ -718,7 +721,12 @@ class DreamerEngine:
         if self.conv is not None:
             self.mlp_backward(N, d_rw, 1, rw_layers, rw_acts + [None], rw_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F)
             with self.span("decoder_bwd"):
-                self.conv.backward_decoder(d_om.view(N, 64, 64, 3), feat, dfeat, self._wbatch["model"])
+                # the decoder's weight-gradient GEMMs (60 % of the pass) are ready here: they run on their own stream
+                # underneath the observe-scan backward (52 CUs) instead of after it
+                self.conv.backward_decoder(d_om.view(N, 64, 64, 3), feat, dfeat, self._wbatch["model_early"])
+                self._s_early.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._s_early):
+                    self._wbatch["model_early"].run()
         elif self.pixel:
             self.mlp_backward(N, d_rw, 1, rw_layers, rw_acts + [None], rw_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F)
             with self.span("decoder_bwd"):
@@ -809,6 +817,8 @@ class DreamerEngine:
             self._dense_wgrads(wb, "encoder", N, enc_dpre, obs_t, d.O, enc_acts, dense_sizes(d.O, d.E))
         with self.span("wgrad_model"):
             wb.run()
+        if self.conv is not None:
+            torch.cuda.current_stream().wait_stream(self._s_early)      # decoder weight gradients (queued above)
         if self.pipeline and self._ev_bh_wm_free is not None:
             # the previous step's imagination / reward-head kernels may still be reading the weights Adam overwrites
             torch.cuda.current_stream().wait_event(self._ev_bh_wm_free)
