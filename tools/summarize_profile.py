@@ -30,7 +30,8 @@ shutil.copy(stats_csv, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 fe, wr, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq")
 mean = lambda xs: sum(xs) / max(1, len(xs))
 names = {"imagine_fwd": "imagine_fwd_kernel", "imagine_bwd": "imagine_bwd_kernel", "observe_fwd": "observe_cfwd_kernel",
-         "observe_bwd": "observe_cbwd_kernel"}
+         "observe_bwd": "observe_cbwd_kernel", "mlp_fwd (all launches, mean)": "mlp_fwd_kernel",
+         "mlp_bwd (all launches, mean)": "mlp_bwd_kernel", "wgrad_wide (all launches, mean)": "wgrad_wide_kernel"}
 traffic = {}
 for key, frag in names.items():
     kn = [k for k in fe if frag in k]
@@ -66,7 +67,7 @@ with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
     for r in rows[:14]:
         f.write(f"| `{r['Name'][:64]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |\n")
     f.write("\nHIP-event averages inside bench.py (ms): " + json.dumps(bench["kernel_ms"]) + "\n\n")
-    f.write("| persistent kernel | HBM bytes/launch (FETCH x2 + WRITE) | L2 hit | MFMA f32 insts | MFMA busy / (CU-cycles used) | wait / stall / active |\n|---|---|---|---|---|---|\n")
+    f.write("| kernel | HBM bytes/launch (FETCH x2 + WRITE) | L2 hit | MFMA f32 insts | MFMA busy / (CU-cycles used) | wait / stall / active |\n|---|---|---|---|---|---|\n")
     for key, t in traffic.items():
         f.write(f"| {key} | {t['hbm_bytes_per_launch'] / 1e6:.1f} MB ({t['fetch_bytes'] / 1e6:.1f} + {t['write_bytes'] / 1e6:.1f}) | "
                 f"{100 * t['l2_hit_rate']:.1f} % | {t['mfma_f32_insts']:.3g} | {t['mfma_busy_cycles']:.3g} | "
