@@ -67,3 +67,41 @@ def test_config_overrides_like_hydra():
     assert cfg["planning_horizon"] == 15 and cfg["kl_balance"] == 0.8 and cfg["free_nats"] == 3.0
     with pytest.raises(KeyError):
         load_config(["not_a_key=1"])
+
+
+def test_wgrad_plan_handles_conv_descriptors_on_the_host():
+    """bd_wgrad_plan is host-only: a pass that mixes 2 450-row GEMMs with gathered conv weight gradients of up to
+    2.4 M rows gets per-GEMM row splits (all multiples of the 16-row stage, every GEMM covered), and inconsistent
+    gather geometry is rejected with a message."""
+    import ctypes as C
+    from big_dreamer_amd import _cabi as cabi
+    from big_dreamer_amd import conv
+
+    def desc(M, N, K, bias, g=None):
+        d = cabi.WgradDesc()
+        d.dpre, d.ldp, d.act1, d.lda1, d.M1, d.act2, d.lda2 = 16, N, 16, K, M, None, 0
+        d.M, d.N, d.K, d.dW, d.ldw, d.db = M, N, K, 16, K, (16 if bias else None)
+        if g:
+            d.g_nseg, d.g_seglen, d.g_gh, d.g_gw, d.g_IH, d.g_IW, d.g_C = g
+        return d
+
+    imgs = 2450
+    descs = [desc(imgs, 600, 200, True), desc(imgs, 200, 1024, False), desc(imgs, 1, 200, True),
+             desc(imgs * 961, 32, 48, True, (4, 12, 31, 31, 64, 64, 3)),            # Conv2d 3->32 k4 on 64x64
+             desc(imgs * 169, 64, 1152, False, (6, 192, 13, 13, 30, 30, 32)),       # ConvT 64->32 k6, 13 -> 30
+             desc(imgs * 4, 256, 2048, True, (4, 512, 2, 2, 6, 6, 128))]
+    arr = (cabi.WgradDesc * len(descs))(*descs)
+    tb, tr, wsf = C.c_int(0), C.c_int(0), C.c_size_t(0)
+    assert cabi.lib.bd_wgrad_plan(arr, len(descs), C.byref(tb), C.byref(tr), C.byref(wsf)) == 0, cabi.lib.bd_last_error()
+    assert tb.value == sum(d.tiles_n * d.tiles_k * d.splits for d in arr) and tr.value > 0 and wsf.value > 0
+    for d in arr:
+        assert d.rows_per % 16 == 0 and d.splits * d.rows_per >= d.M and (d.splits - 1) * d.rows_per < d.M
+        assert d.tiles_n * 13 * 16 >= d.N and d.tiles_k * 13 * 16 >= d.K
+    assert max(d.rows_per for d in arr) < 20000, "conv GEMMs must not leave millions of rows to one workgroup"
+    bad = (cabi.WgradDesc * 1)(desc(imgs * 961, 32, 48, True, (4, 12, 31, 31, 60, 64, 3)))      # windows leave the image
+    assert cabi.lib.bd_wgrad_plan(bad, 1, C.byref(tb), C.byref(tr), C.byref(wsf)) != 0
+    assert b"gather geometry" in cabi.lib.bd_last_error()
+    # geometry helpers of the conv host module
+    assert [conv.conv_out(s, 4) for s in (64, 31, 14, 6)] == [31, 14, 6, 2]
+    assert [conv.convT_out(s, k) for s, k in ((1, 5), (5, 5), (13, 6), (30, 6))] == [5, 13, 30, 64]
+    assert (conv.taps(5, 0), conv.taps(5, 1), conv.taps(6, 0), conv.taps(6, 1), conv.taps(4, 1)) == (3, 2, 3, 3, 2)
