@@ -99,6 +99,13 @@ class ImagineBwdArgs(C.Structure):
         ("dentropy", F32)] + _ptr_fields(["d_actor_pre", "d_actor_out"]))
 
 
+class PlanArgs(C.Structure):
+    _fields_ = ([(n, I32) for n in ("rows", "H", "cand", "Be", "S", "A", "Hd")] + _ptr_fields(
+        ["w_embed_s", "w_embed_a", "b_embed", "w_ir", "w_iz", "w_in", "w_hr", "w_hz", "w_hn", "b_ih", "b_hh", "w_p1",
+         "b_p1", "w_p2m", "w_p2s", "b_p2"]) + [("w_r", P * 5), ("b_r", P * 5), ("min_std", F32)] + _ptr_fields(
+        ["init_belief", "init_state", "act_mean", "act_std", "eps_action", "eps_state", "actions", "returns", "feat"]))
+
+
 class ConvArgs(C.Structure):
     _fields_ = [("in_", P), ("out", P), ("w", P), ("bias", P),
                 ("imgs", I32), ("gh", I32), ("gw", I32), ("N", I32), ("K", I32),
@@ -132,6 +139,8 @@ _SIGS = {
     "bd_imagine_forward": (I32, [C.POINTER(ImagineFwdArgs), P]),
     "bd_imagine_backward": (I32, [C.POINTER(ImagineBwdArgs), P]),
     "bd_lambda_return_forward": (I32, [P, P, I32, I32, F32, F32, P, P]),
+    "bd_plan_rollout": (I32, [C.POINTER(PlanArgs), P]),
+    "bd_cem_refit": (I32, [P, I32, P, I32, I32, I32, I32, I32, P, P, P]),
     "bd_lambda_return_backward": (I32, [P, F32, I32, I32, F32, F32, P, P, P]),
     "bd_normal_nll": (I32, [P, I32, P, I32, I32, I32, F32, P, I32, P, I32, P, P]),
     "bd_kl_forward": (I32, [P, P, P, P, I32, I32, F32, I32, P, I32, P, P]),

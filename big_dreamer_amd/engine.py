@@ -584,6 +584,61 @@ class DreamerEngine:
         return ifeat, ent, act
 
     # ------------------------------------------------------------------------------------------ train step
+    def plan(self, belief: torch.Tensor, state: torch.Tensor, horizon: int, iters: int, candidates: int, top: int,
+             eps_action: torch.Tensor, eps_state: torch.Tensor, trace: Optional[list] = None) -> torch.Tensor:
+        """MPCPlanner.forward (src/planner.py:28-90) on the current stream: `iters` x (bd_plan_rollout, bd_cem_refit).
+        belief (B,Be), state (B,S); eps_action (iters,H,B,candidates,A); eps_state (iters,H,B*candidates,S).
+        Returns the action-belief mean of every planning step, (H,B,A); row 0 is the planner's answer."""
+        d, pk = self.d, self.pk
+        tm = lambda n: self.W("transition_model", n)
+        B = belief.shape[0]
+        rows = B * candidates
+        mean = self.buf("plan_mean", horizon, B, d.A)
+        std = self.buf("plan_std", horizon, B, d.A)
+        mean.zero_()                                    # q(a_t:t+H) ~ N(0, I), src/planner.py:41-46
+        std.fill_(1.0)
+        actions = self.buf("plan_actions", horizon, rows, d.A)
+        returns = self.buf("plan_returns", rows)
+        a = cabi.PlanArgs()
+        a.rows, a.H, a.cand, a.Be, a.S, a.A, a.Hd = rows, horizon, candidates, d.Be, d.S, d.A, d.Hd
+        a.w_embed_s, a.w_embed_a, a.b_embed = ptr(pk["embed_s"]), ptr(pk["embed_a"]), ptr(tm("fc_embed_state_action.0.bias"))
+        a.w_ir, a.w_iz, a.w_in = ptr(pk["ir"]), ptr(pk["iz"]), ptr(pk["in"])
+        a.w_hr, a.w_hz, a.w_hn = ptr(pk["hr"]), ptr(pk["hz"]), ptr(pk["hn"])
+        a.b_ih, a.b_hh = ptr(tm("rnn.bias_ih")), ptr(tm("rnn.bias_hh"))
+        a.w_p1, a.b_p1 = ptr(pk["p1"]), ptr(tm("belief_prior.model.0.bias"))
+        a.w_p2m, a.w_p2s, a.b_p2 = ptr(pk["p2m"]), ptr(pk["p2s"]), ptr(tm("belief_prior.model.2.bias"))
+        for l in range(DENSE_LAYERS + 1):
+            a.w_r[l] = ptr(pk[f"rew{l}"])
+            a.b_r[l] = ptr(self.W("reward_model", f"model.{2 * l}.bias"))
+        a.min_std = self.hp["min_std_dev"]
+        a.init_belief, a.init_state = ptr(belief), ptr(state)
+        a.act_mean, a.act_std, a.actions = ptr(mean), ptr(std), ptr(actions)
+        # Reward model inside the rollout (one return per candidate leaves the CU) once the candidate tiles fill the
+        # chip; below that the rollout is latency bound, so it writes [h'; s'] and the reward model runs as one dense
+        # chain over all H x rows rows (measured at B=1: 0.98 -> see DESIGN.md; BD_PLAN_FUSE=0/1 forces either form).
+        fuse_env = os.environ.get("BD_PLAN_FUSE", "")
+        fuse = (rows >= 16 * 256) if fuse_env == "" else fuse_env != "0"
+        F = d.Be + d.S
+        if fuse:
+            a.returns, a.feat = ptr(returns), None
+        else:
+            feat = self.buf("plan_feat", horizon * rows, F)
+            a.returns, a.feat = None, ptr(feat)
+        st = cabi.stream()
+        for it in range(iters):
+            a.eps_action, a.eps_state = ptr(eps_action[it]), ptr(eps_state[it])
+            cabi.check(lib.bd_plan_rollout(C.byref(a), st))
+            if fuse:
+                ret, steps = returns, 1
+            else:
+                ret, _, _ = self.dense_forward("reward_model", "rew", "plan_rew", feat, F, horizon * rows, 1)
+                steps = horizon
+            if trace is not None:
+                trace.append(ret.view(steps, rows).sum(dim=0))
+            cabi.check(lib.bd_cem_refit(ptr(ret), steps, ptr(actions), horizon, B, candidates, top, d.A, ptr(mean),
+                                        ptr(std), st))
+        return mean
+
     def make_noise(self, B: int, part: str = "all") -> Dict[str, torch.Tensor]:
         """On-device standard-normal noise for one step (perf mode; parity tests pass explicit arrays), drawn on the
         current stream.  part: "wm" (observe scan), "bh" (imagination) or "all"."""
@@ -667,6 +722,20 @@ class DreamerEngine:
             self._ev_bh_done[par] = torch.cuda.Event()
             self._ev_bh_done[par].record(s_bh)
         return self.logs() if sync_logs else {}
+
+    def world_model_step(self, batch: Dict[str, torch.Tensor], noise: Optional[Dict[str, torch.Tensor]] = None,
+                         sync_logs: bool = True) -> Dict[str, float]:
+        """Planet.train_step (src/planet.py:310-368): dynamics learning only, on the caller's stream."""
+        self.join()
+        obs = batch["observations"]
+        T, B = obs.shape[0] - 1, obs.shape[1]
+        self._timer_tick += 1
+        self._dynamics_phase(batch, noise if noise is not None else self.make_noise(B, "wm"), "")
+        self._counts = dict(N=T * B, Mi=1, S=self.d.S, sum_form=int(self.hp["kl_balance"] == -1))
+        if not sync_logs:
+            return {}
+        return {k: v for k, v in self.logs().items() if k in ("observation_loss", "reward_loss", "kl_loss", "model_loss",
+                                                              "grad_norm_model")}
 
     def _dynamics_phase(self, batch: Dict[str, torch.Tensor], noise: Dict[str, torch.Tensor], feat_tag: str) -> torch.Tensor:
         """Dynamics learning (src/dreamer.py:263-302) on the current stream; returns the posterior features."""

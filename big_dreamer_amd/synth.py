@@ -212,3 +212,16 @@ def make_noise(d: Dims, seed: int = 0) -> Dict[str, np.ndarray]:
         img[t] = ns.normal((d.N, d.S))
     return {"obs_prior": obs_prior, "obs_post": obs_post, "action": act, "entropy": ent,
             "img_prior": img}
+
+
+def make_planner_noise(d: Dims, B: int, horizon: int, iters: int, candidates: int, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Noise of one MPCPlanner.forward in reference order (src/planner.py:53-65): per CEM iteration the action draws
+    (H,B,candidates,A), then one prior-state draw (B*candidates,S) per rollout step (src/models.py:256)."""
+    ns = NoiseStream(seed)
+    act = np.empty((iters, horizon, B, candidates, d.A), np.float32)
+    st = np.empty((iters, horizon, B * candidates, d.S), np.float32)
+    for it in range(iters):
+        act[it] = ns.normal((horizon, B, candidates, d.A))
+        for t in range(horizon):
+            st[it, t] = ns.normal((B * candidates, d.S))
+    return {"action": act, "state": st}

@@ -310,6 +310,39 @@ int bd_lambda_return_forward(const float* reward, const float* value, int Hm, in
 int bd_lambda_return_backward(const float* dreturns, float dret_const, int Hm, int N, float discount,
                               float lambda_, float* dreward, float* dvalue, void* stream);
 
+/* ---- CEM planner: MPCPlanner.forward (src/planner.py:28-90) -------------------------------------
+ * One CEM iteration = bd_plan_rollout + bd_cem_refit.  rows = B * cand candidate action sequences (row = b * cand + c);
+ * the rollout forms a_t = act_mean[t][b] + act_std[t][b] * eps_action[t][row] (src/planner.py:60-62), runs the
+ * prior-only RSSM step (src/models.py:241-256, embeddings=None, nonterminals=None) and the reward model
+ * (src/models.py:365-408) per step in LDS and writes the actions [H x rows x A] and the summed predicted reward per
+ * candidate (src/planner.py:68-72).  w_r[0] is the reward model's first layer packed over K = Be+S. */
+typedef struct {
+    int rows, H, cand, Be, S, A, Hd;
+    const float* w_embed_s; const float* w_embed_a; const float* b_embed;
+    const float* w_ir; const float* w_iz; const float* w_in;
+    const float* w_hr; const float* w_hz; const float* w_hn;
+    const float* b_ih; const float* b_hh;
+    const float* w_p1; const float* b_p1;                 /* belief_prior.model.0 */
+    const float* w_p2m; const float* w_p2s; const float* b_p2;   /* belief_prior.model.2 rows [:S] / [S:] */
+    const float* w_r[5]; const float* b_r[5];             /* reward_model.model.{0,2,4,6,8} */
+    float min_std;
+    const float* init_belief;   /* [B x Be]  (every candidate of environment b starts from row b, src/planner.py:37) */
+    const float* init_state;    /* [B x S]   */
+    const float* act_mean;      /* [H x B x A] */
+    const float* act_std;       /* [H x B x A] */
+    const float* eps_action;    /* [H x rows x A]  the torch.randn draws of src/planner.py:53-59 */
+    const float* eps_state;     /* [H x rows x S]  the prior-state draws (src/models.py:72) */
+    float* actions;             /* out [H x rows x A] */
+    float* returns;             /* out [rows]; NULL: skip the reward model and write `feat` instead */
+    float* feat;                /* out [H x rows x (Be+S)] ([h'; s'] per step) or NULL */
+} bd_plan_args;
+int bd_plan_rollout(const bd_plan_args* a, void* stream);
+/* Re-fit the action belief to the `top` best candidates of every environment (src/planner.py:74-87):
+ * mean / stdev [H x B x A] <- mean and biased standard deviation over the selected action sequences.
+ * returns is [ret_steps x B*cand]: ret_steps = 1 for summed returns, H for per-step reward predictions (summed here). */
+int bd_cem_refit(const float* returns, int ret_steps, const float* actions, int H, int B, int cand, int top, int A,
+                 float* mean, float* stdev, void* stream);
+
 /* ---- losses (src/planet.py:252-284, src/dreamer.py:110-146,342-383) ---------------------------
  * Reductions write RAW SUMS into a small device "scalar board" (float array); the host turns them
  * into the logged means after one D2H copy per step, and multi-GPU runs all-reduce the board's KL slot

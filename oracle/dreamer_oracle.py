@@ -267,6 +267,37 @@ def adam_step(params, grads, st: AdamState, lr: float, eps: float, weight_decay:
 
 
 # ----------------------------------------------------------------------------------------------
+# MPCPlanner.forward (src/planner.py:28-90): cross-entropy method over prior-only rollouts
+# ----------------------------------------------------------------------------------------------
+def mpc_planner(P, belief: Tensor, state: Tensor, action_size: int, planning_horizon: int, optimisation_iters: int,
+                candidates: int, top_candidates: int, eps_action: Tensor, eps_state: Tensor, trace: Optional[list] = None):
+    """belief (B,Be), state (B,S) -> first action mean (B,A).
+
+    eps_action (iters, H, B, candidates, A): the ``torch.randn`` draws of src/planner.py:53-59;
+    eps_state (iters, H, B*candidates, S): the prior-state draws of the rollout (src/models.py:256 -> :72).
+    ``trace`` (optional list) receives per iteration (returns (B*candidates,), action_mean, action_std)."""
+    B, Hb, Z = belief.size(0), belief.size(1), state.size(1)
+    belief = belief.unsqueeze(1).expand(B, candidates, Hb).reshape(-1, Hb)                        # :37
+    state = state.unsqueeze(1).expand(B, candidates, Z).reshape(-1, Z)                            # :38
+    mean = torch.zeros(planning_horizon, B, 1, action_size)                                       # :41-43
+    std = torch.ones(planning_horizon, B, 1, action_size)                                         # :44-46
+    for it in range(optimisation_iters):
+        actions = (mean + std * eps_action[it]).view(planning_horizon, B * candidates, action_size)   # :60-62
+        beliefs, states, _, _, _ = transition_forward(P["transition_model"], state, actions, belief, None, None,
+                                                      eps_state[it], None)                        # :65
+        returns = dense_on_features(beliefs.view(-1, Hb), states.view(-1, Z), P["reward_model"]) \
+            .view(planning_horizon, -1).sum(dim=0)                                                # :68-72
+        _, topk = returns.reshape(B, candidates).topk(top_candidates, dim=1, largest=True, sorted=False)   # :74-76
+        topk = topk + candidates * torch.arange(0, B, dtype=torch.int64).unsqueeze(1)             # :78-80
+        best = actions[:, topk.view(-1)].reshape(planning_horizon, B, top_candidates, action_size)   # :81-83
+        mean = best.mean(dim=2, keepdim=True)                                                     # :86
+        std = best.std(dim=2, unbiased=False, keepdim=True)                                       # :87
+        if trace is not None:
+            trace.append((returns.detach().clone(), mean.detach().clone(), std.detach().clone()))
+    return mean[0].squeeze(dim=1)                                                                 # :90
+
+
+# ----------------------------------------------------------------------------------------------
 # the whole step: Dreamer.train_step (src/dreamer.py:253-393)
 # ----------------------------------------------------------------------------------------------
 DEFAULT_HP = dict(
@@ -326,6 +357,27 @@ class OracleDreamer:
                      prior_stds=prior_params[1], posterior_states=post_states, posterior_means=post_params[0],
                      posterior_stds=post_params[1], reward_pred=rew_pred)
         return model_loss, obs_loss, rew_loss, kl, inter
+
+    def planet_train_step(self, batch_np, noise_np, keep: bool = True):
+        """Planet.train_step (src/planet.py:310-368): dynamics learning only; its ``_kl_loss`` (src/planet.py:286-308)
+        is always the summed form ``max(KL.sum(2), free_nats).mean()`` whatever ``kl_balance`` says."""
+        hp = self.hp
+        assert hp["kl_balance"] == -1, "Planet._kl_loss is the kl_balance == -1 form"
+        batch = {k: torch.as_tensor(v) for k, v in batch_np.items()}
+        noise = {k: torch.as_tensor(v) for k, v in noise_np.items()}
+        model_loss, obs_loss, rew_loss, kl, inter = self.world_model_forward(batch, noise)
+        logs = dict(observation_loss=obs_loss.item(), reward_loss=rew_loss.item(), kl_loss=kl.item(),
+                    model_loss=model_loss.item())
+        grads = torch.autograd.grad(model_loss, self.model_params, allow_unused=True)
+        grads = [torch.zeros_like(p) if g is None else g.clone() for g, p in zip(grads, self.model_params)]
+        model_grads = [g.clone() for g in grads] if keep else None
+        gn_model = clip_grad_norm_(grads, hp["grad_clip_norm"])
+        adam_step(self.model_params, grads, self.opt["model"], hp["model_learning_rate"], hp["adam_epsilon"],
+                  hp["weight_decay"])
+        if keep:
+            self.last = dict(inter={k: t.detach() for k, t in inter.items()}, model_grads=model_grads,
+                             grad_norms=dict(model=gn_model.item()))
+        return logs
 
     def train_step(self, batch_np, noise_np, keep: bool = True):
         hp, P = self.hp, self.P

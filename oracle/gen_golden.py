@@ -85,14 +85,15 @@ class Inject:
 
     def __enter__(self):
         import torch.distributions.normal as tdn
-        self._rl, self._sn = torch.randn_like, tdn._standard_normal
+        self._rl, self._sn, self._rn = torch.randn_like, tdn._standard_normal, torch.randn
         torch.randn_like = lambda x, **kw: torch.from_numpy(self.s.normal(x.shape))
+        torch.randn = lambda *size, **kw: torch.from_numpy(self.s.normal(size))          # src/planner.py:53
         tdn._standard_normal = lambda shape, dtype, device: torch.from_numpy(self.s.normal(tuple(shape)))
         return self
 
     def __exit__(self, *a):
         import torch.distributions.normal as tdn
-        torch.randn_like, tdn._standard_normal = self._rl, self._sn
+        torch.randn_like, tdn._standard_normal, torch.randn = self._rl, self._sn, self._rn
 
 
 def build_agent(dreamer_mod, d, P, **over):
@@ -248,6 +249,75 @@ def run_pixel_preprocess():
     print(f"wrote {path}")
 
 
+def run_planner(dreamer_mod, name: str, d: synth.Dims, B: int, horizon: int, iters: int, candidates: int, top: int,
+                seed: int, full: bool):
+    """MPCPlanner.forward (src/planner.py:28-90) with the reference's transition / reward modules on synthetic
+    weights; per-iteration candidate returns are captured with a forward hook on the reward model."""
+    import planner as ref_planner
+    P = synth.make_params(d, seed)
+    agent = build_agent(dreamer_mod, d, P)
+    mpc = ref_planner.MPCPlanner(d.A, horizon, iters, candidates, top, agent.transition_model, agent.reward_model)
+    rng = np.random.Generator(np.random.PCG64(seed + 500))
+    belief = rng.standard_normal((B, d.Be), dtype=np.float32) * 0.5
+    state = rng.standard_normal((B, d.S), dtype=np.float32)
+    rets = []
+    hook = agent.reward_model.register_forward_hook(
+        lambda m, i, o: rets.append(o.detach().view(horizon, -1).sum(dim=0).numpy().copy()))
+    ns = synth.NoiseStream(seed)
+    with torch.no_grad(), Inject(ns):
+        action = mpc(torch.from_numpy(belief), torch.from_numpy(state))
+    hook.remove()
+    ns2 = synth.NoiseStream(seed)
+    for it in range(iters):
+        ns2.normal((horizon, B, candidates, d.A))
+        for t in range(horizon):
+            ns2.normal((B * candidates, d.S))
+    assert ns.calls == ns2.calls, "reference planner RNG order differs from synth.make_planner_noise"
+    out = {"belief": belief, "state": state, "action": t2n(action),
+           "meta": np.array([B, horizon, iters, candidates, top, seed])}
+    for it, r in enumerate(rets):
+        store(out, f"returns{it}", r, full)
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def run_planet(name: str, d: synth.Dims, seed: int):
+    """Planet.train_step (src/planet.py:310-368) x2: dynamics learning with the summed free-nats KL."""
+    import planet as ref_planet
+    P = synth.make_params(d, seed)
+    batch = synth.make_batch(d, seed)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    params = ref_params(d, free_nats=0.05)
+    params["algorithm"] = "planet"
+    agent = ref_planet.Planet(params, FakeEnv(d))
+    for mod in ("transition_model", "observation_model", "reward_model", "encoder"):
+        getattr(agent, mod).load_state_dict({k: torch.from_numpy(v.copy()) for k, v in P[mod].items()})
+    agent.buffer.sample = lambda n, L: [tb["observations"], tb["actions"], tb["rewards"], tb["nonterminals"]]
+    out = {}
+    for step in range(2):
+        with Inject(synth.NoiseStream(seed + step)):
+            logs = agent.train_step()
+        for k, v in logs.items():
+            out[f"step{step}.log.{k}"] = np.array(v, dtype=np.float64)
+        for mod in ("transition_model", "observation_model", "reward_model", "encoder"):
+            for k, p in getattr(agent, mod).state_dict().items():
+                out[f"step{step}.param.{mod}.{k}"] = t2n(p)
+            for k, p in getattr(agent, mod).named_parameters():
+                out[f"step{step}.grad.{mod}.{k}"] = t2n(p.grad)
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def main_planner(dreamer_mod):
+    run_planner(dreamer_mod, "planner_tiny", synth.TINY, B=2, horizon=5, iters=4, candidates=64, top=8, seed=6, full=True)
+    # the reference's defaults (conf/config.yaml:31,63-66) at the config-2 model size, one environment
+    run_planner(dreamer_mod, "planner_config2", synth.CONFIG2, B=1, horizon=15, iters=10, candidates=1000, top=100,
+                seed=7, full=False)
+    run_planet("tiny_planet", synth.TINY, seed=8)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -263,7 +333,13 @@ def main():
     run_pixel_preprocess()
     run_config(dreamer_mod, "config1", synth.CONFIG1, full=False)
     run_config(dreamer_mod, "config2", synth.CONFIG2, full=False)
+    main_planner(dreamer_mod)
 
 
 if __name__ == "__main__":
-    main()
+    if "--planner-only" in sys.argv:       # regenerate only the planner / PlaNet vectors
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        main_planner(_import_reference()[0])
+    else:
+        main()

@@ -25,15 +25,17 @@ def my_app(argv):
     np.random.seed(params["seed"] + rank)
     torch.manual_seed(params["seed"])                 # identical initial weights on every rank
     random.seed(params["seed"] + rank)
-    if params["algorithm"] not in ("dreamer", "dreamerV2"):      # planet (MPC) is outside this build's hot path
+    if params["algorithm"] not in ("planet", "dreamer", "dreamerV2"):     # as src/main.py:73-81
         raise NotImplementedError(f'algorithm {params["algorithm"]} is not yet implemented.')
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
     if world > 1:
         torch.distributed.init_process_group("nccl")
     from big_dreamer_amd.dreamer import Dreamer, DreamerV2
+    from big_dreamer_amd.planet import Planet
     from big_dreamer_amd.env import Env
     env = Env(params)
-    model = (DreamerV2 if params["algorithm"] == "dreamerV2" else Dreamer)(params, env, world_size=world)
+    agent_cls = {"planet": Planet, "dreamer": Dreamer, "dreamerV2": DreamerV2}[params["algorithm"]]
+    model = agent_cls(params, env, world_size=world)
     torch.manual_seed(params["seed"] + rank)
     env_steps, num_episodes = model.randomly_initialize_replay_buffer()
     if rank == 0:
@@ -50,8 +52,8 @@ def my_app(argv):
             for _ in range(params["collect_interval"]):
                 logs = model.train_step()
             logs["weight_update_per_sec"] = params["collect_interval"] / (time.time() - t0)
-        if step % params["ActorCritic"]["slow_critic_update_interval"]:       # cadence as in the reference
-            model.update_critic()
+        if params["algorithm"] != "planet" and step % params["ActorCritic"]["slow_critic_update_interval"]:
+            model.update_critic()                                              # cadence as in the reference (:110-112)
         belief, posterior_state, action, next_observation, reward, done = model.update_belief_and_act(
             env, belief, posterior_state, action, observation, explore=True)
         model.buffer.append(observation, action.cpu()[0], reward, done)

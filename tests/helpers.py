@@ -64,3 +64,10 @@ def compare_tensor(g, key, got, full, atol, rtol):
                      atol * n, rtol)
         # plain sums cancel, so bound their error by the abssum scale
         assert abs(got.astype(np.float64).sum() - float(g[key + ".sum"])) <= atol * n + rtol * float(g[key + ".abssum"])
+
+
+# MPCPlanner golden cases: name -> (Dims, B, horizon, iters, candidates, top, seed, stored in full?)
+PLANNER_CASES = {
+    "planner_tiny": (synth.TINY, 2, 5, 4, 64, 8, 6, True),
+    "planner_config2": (synth.CONFIG2, 1, 15, 10, 1000, 100, 7, False),
+}

@@ -89,3 +89,47 @@ def test_train_steps(name):
             for k, p in od.P[mod].items():
                 # one Adam step moves a weight by <= lr (2e-4): weights must agree to well below that
                 compare_tensor(g, f"step{step}.param.{mod}.{k}", p.detach().numpy(), full, atol=2e-6, rtol=1e-6)
+
+
+from tests.helpers import PLANNER_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(PLANNER_CASES))
+def test_mpc_planner_against_reference(name):
+    """MPCPlanner.forward (src/planner.py:28-90): candidate returns of every CEM iteration and the planned action vs
+    the reference run on the same injected noise.  Returns are sums of H reward predictions after an H-step
+    recurrence: 2e-5 abs; the action is a mean over the selected candidates: 1e-5."""
+    d, B, H, iters, cand, top, seed, full = PLANNER_CASES[name]
+    g = load_golden(name)
+    assert list(g["meta"]) == [B, H, iters, cand, top, seed]
+    P = {m: {k: torch.as_tensor(v) for k, v in sd.items()} for m, sd in synth.make_params(d, seed).items()}
+    nz = synth.make_planner_noise(d, B, H, iters, cand, seed)
+    trace = []
+    with torch.no_grad():
+        act = O.mpc_planner(P, torch.as_tensor(g["belief"]), torch.as_tensor(g["state"]), d.A, H, iters, cand, top,
+                            torch.as_tensor(nz["action"]), torch.as_tensor(nz["state"]), trace)
+    for it, (ret, _, _) in enumerate(trace):
+        compare_tensor(g, f"returns{it}", ret.numpy(), full, 2e-5, 1e-5)
+    assert_close("action", act.numpy(), g["action"], 1e-5, 1e-5)
+
+
+def test_planet_train_steps_against_reference():
+    """Planet.train_step (src/planet.py:310-368) x2: logs, clipped gradients and post-Adam weights."""
+    d, seed = synth.TINY, 8
+    g = load_golden("tiny_planet")
+    P = synth.make_params(d, seed)
+    batch = synth.make_batch(d, seed)
+    od = O.OracleDreamer(P, dict(kl_balance=-1, free_nats=0.05, planning_horizon=d.H))
+    for step in range(2):
+        logs = od.planet_train_step(batch, synth.make_noise(d, seed + step))
+        for k, v in logs.items():
+            assert_close(f"step{step}.{k}", v, g[f"step{step}.log.{k}"], 2e-6, 2e-5)
+        coef = min(1.0, od.hp["grad_clip_norm"] / (od.last["grad_norms"]["model"] + 1e-6))
+        i = 0
+        for mod in O.MODEL_MODULES:
+            for k, p in od.P[mod].items():
+                assert_close(f"step{step}.grad.{mod}.{k}", (od.last["model_grads"][i] * coef).numpy(),
+                             g[f"step{step}.grad.{mod}.{k}"], 2e-6, 1e-4)
+                assert_close(f"step{step}.param.{mod}.{k}", p.detach().numpy(), g[f"step{step}.param.{mod}.{k}"],
+                             2e-6, 1e-5)
+                i += 1
