@@ -139,6 +139,10 @@ _SIGS = {
     "bd_imagine_forward": (I32, [C.POINTER(ImagineFwdArgs), P]),
     "bd_imagine_backward": (I32, [C.POINTER(ImagineBwdArgs), P]),
     "bd_lambda_return_forward": (I32, [P, P, I32, I32, F32, F32, P, P]),
+    "bd_categorical_head_forward": (I32, [P, P, I32, I32, I32, P, P, P]),
+    "bd_categorical_head_backward": (I32, [P, P, I32, I32, I32, P, P]),
+    "bd_kl_categorical_forward": (I32, [P, P, I32, I32, I32, F32, I32, P, I32, P, P]),
+    "bd_kl_categorical_backward": (I32, [P, P, I32, I32, I32, F32, F32, F32, F32, P, I32, P, P, P]),
     "bd_plan_rollout": (I32, [C.POINTER(PlanArgs), P]),
     "bd_cem_refit": (I32, [P, I32, P, I32, I32, I32, I32, I32, P, P, P]),
     "bd_lambda_return_backward": (I32, [P, F32, I32, I32, F32, F32, P, P, P]),

@@ -221,6 +221,202 @@ __global__ __launch_bounds__(256) void polyak_kernel(float* __restrict__ t, cons
         t[i] = s[i] * w + t[i] * (1.f - w);
 }
 
+// ---- Categorical latents (CategoricalBeliefModel, src/models.py:101-117; KL branch src/dreamer.py:102-106,131-144) ----
+// rows x D groups of C classes (reference: 32 x 32).  A 32-lane half wave owns one group; a lane holds classes
+// c = l, l+32, ... (C <= 128).  Reductions are xor-shuffles with offsets < 32, which stay inside the half wave.
+constexpr int kCatPer = 4;     // classes per lane
+
+__device__ __forceinline__ float half_max(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// normalised log-probabilities of one group, as Categorical(logits=...) keeps them: x - logsumexp(x)
+// (torch/distributions/categorical.py); lp[i] is class l + 32 i (-inf beyond C)
+__device__ __forceinline__ void group_log_softmax(const float* __restrict__ x, int C, int l, float (&lp)[kCatPer]) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kCatPer; ++i) {
+        const int c = l + 32 * i;
+        lp[i] = c < C ? x[c] : -INFINITY;
+        m = fmaxf(m, lp[i]);
+    }
+    m = half_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kCatPer; ++i) s += (l + 32 * i < C) ? expf(lp[i] - m) : 0.f;
+    const float lse = m + logf(half_sum(s));
+#pragma unroll
+    for (int i = 0; i < kCatPer; ++i) lp[i] -= lse;
+}
+
+// state = one_hot(argmax(probs / q)) with q ~ Exp(1): torch.multinomial's single-draw path (ATen
+// native/Distributions.cpp: `q = empty_like(probs).exponential_(1); argmax(probs / q)`), reached from
+// OneHotCategoricalStraightThrough.rsample(); the straight-through term probs - probs.detach() is exactly zero.
+__global__ __launch_bounds__(256) void cat_head_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ q,
+                                                           size_t groups, int C, float* __restrict__ state,
+                                                           float* __restrict__ probs) {
+    const int l = threadIdx.x & 31;
+    for (size_t g = (size_t)blockIdx.x * 8 + (threadIdx.x >> 5); g < groups; g += (size_t)gridDim.x * 8) {
+        const size_t base = g * C;
+        float lp[kCatPer];
+        group_log_softmax(logits + base, C, l, lp);
+        // probs = softmax(normalised logits) (logits_to_probs)
+        float pr[kCatPer], m = -INFINITY, s = 0.f;
+#pragma unroll
+        for (int i = 0; i < kCatPer; ++i) m = fmaxf(m, lp[i]);
+        m = half_max(m);
+#pragma unroll
+        for (int i = 0; i < kCatPer; ++i) {
+            pr[i] = (l + 32 * i < C) ? expf(lp[i] - m) : 0.f;
+            s += pr[i];
+        }
+        s = half_sum(s);
+        float best = -INFINITY;
+        int arg = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < kCatPer; ++i) {
+            const int c = l + 32 * i;
+            if (c < C) {
+                pr[i] /= s;
+                probs[base + c] = pr[i];
+                const float r = pr[i] / q[base + c];
+                if (r > best) { best = r; arg = c; }       // first maximum wins (argmax)
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oa = __shfl_xor(arg, o, 64);
+            if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+        }
+#pragma unroll
+        for (int i = 0; i < kCatPer; ++i) {
+            const int c = l + 32 * i;
+            if (c < C) state[base + c] = (c == arg) ? 1.f : 0.f;
+        }
+    }
+}
+
+// straight-through: d state / d probs = I, probs = softmax(logits): dlogits = p * (g - sum_c p g)
+__global__ __launch_bounds__(256) void cat_head_bwd_kernel(const float* __restrict__ dstate, const float* __restrict__ probs,
+                                                           size_t groups, int C, float* __restrict__ dlogits) {
+    const int l = threadIdx.x & 31;
+    for (size_t g = (size_t)blockIdx.x * 8 + (threadIdx.x >> 5); g < groups; g += (size_t)gridDim.x * 8) {
+        const size_t base = g * C;
+        float pr[kCatPer], gr[kCatPer], dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < kCatPer; ++i) {
+            const int c = l + 32 * i;
+            pr[i] = c < C ? probs[base + c] : 0.f;
+            gr[i] = c < C ? dstate[base + c] : 0.f;
+            dot += pr[i] * gr[i];
+        }
+        dot = half_sum(dot);
+#pragma unroll
+        for (int i = 0; i < kCatPer; ++i) {
+            const int c = l + 32 * i;
+            if (c < C) dlogits[base + c] = pr[i] * (gr[i] - dot);
+        }
+    }
+}
+
+// KL(q || p) of one group from normalised log-probabilities (torch.distributions.kl._kl_categorical_categorical:
+// t = q.probs * (q.logits - p.logits); t[p.probs == 0] = inf; t[q.probs == 0] = 0)
+__device__ __forceinline__ float group_kl(const float (&lq)[kCatPer], const float (&lp)[kCatPer], int C, int l) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kCatPer; ++i) {
+        if (l + 32 * i < C) {
+            const float qv = expf(lq[i]), pv = expf(lp[i]);
+            float t = qv * (lq[i] - lp[i]);
+            if (pv == 0.f) t = INFINITY;
+            if (qv == 0.f) t = 0.f;
+            s += t;
+        }
+    }
+    return half_sum(s);
+}
+
+// unit of work = one group (balanced form: mean over all rows x D groups) or one row (sum form: max(sum_D, free_nats))
+__global__ __launch_bounds__(256) void cat_kl_fwd_kernel(const float* __restrict__ ql, const float* __restrict__ pl, int rows,
+                                                         int D, int C, float free_nats, int sum_form,
+                                                         double* __restrict__ partials) {
+    __shared__ double red[kWaves > 4 ? kWaves : 4];
+    const int l = threadIdx.x & 31;
+    const size_t units = sum_form ? (size_t)rows : (size_t)rows * D;
+    const int per = sum_form ? D : 1;
+    double acc = 0.0;
+    for (size_t u = (size_t)blockIdx.x * 8 + (threadIdx.x >> 5); u < units; u += (size_t)gridDim.x * 8) {
+        float rs = 0.f;
+        for (int d = 0; d < per; ++d) {
+            const size_t base = (u * per + d) * C;
+            float lq[kCatPer], lp[kCatPer];
+            group_log_softmax(ql + base, C, l, lq);
+            group_log_softmax(pl + base, C, l, lp);
+            rs += group_kl(lq, lp, C, l);
+        }
+        if (l == 0) acc += (double)(sum_form ? fmaxf(rs, free_nats) : rs);
+    }
+    acc = block_sum_d(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// balanced: lhs = KL(sg(post) || prior) -> d prior = p - q;  rhs = KL(post || sg(prior)) -> d post = q (lq - lp - KL)
+__global__ __launch_bounds__(256) void cat_kl_bwd_kernel(const float* __restrict__ ql, const float* __restrict__ pl, int rows,
+                                                         int D, int C, float free_nats, float kl_balance, float weight,
+                                                         float inv_count, const float* __restrict__ scalars, int slot,
+                                                         float* __restrict__ dql, float* __restrict__ dpl) {
+    const int l = threadIdx.x & 31;
+    const bool sum_form = kl_balance == -1.f;
+    const size_t units = sum_form ? (size_t)rows : (size_t)rows * D;
+    const int per = sum_form ? D : 1;
+    float fq, fp;
+    if (!sum_form) {
+        const float f = max_grad(scalars[slot] * inv_count, free_nats) * weight * inv_count;
+        fp = kl_balance * f;
+        fq = (1.f - kl_balance) * f;
+    } else {
+        fq = fp = weight / (float)rows;
+    }
+    for (size_t u = (size_t)blockIdx.x * 8 + (threadIdx.x >> 5); u < units; u += (size_t)gridDim.x * 8) {
+        float f = 1.f;
+        if (sum_form) {
+            float rs = 0.f;
+            for (int d = 0; d < per; ++d) {
+                const size_t base = (u * per + d) * C;
+                float lq[kCatPer], lp[kCatPer];
+                group_log_softmax(ql + base, C, l, lq);
+                group_log_softmax(pl + base, C, l, lp);
+                rs += group_kl(lq, lp, C, l);
+            }
+            f = max_grad(rs, free_nats);
+        }
+        for (int d = 0; d < per; ++d) {
+            const size_t base = (u * per + d) * C;
+            float lq[kCatPer], lp[kCatPer];
+            group_log_softmax(ql + base, C, l, lq);
+            group_log_softmax(pl + base, C, l, lp);
+            const float kl = group_kl(lq, lp, C, l);
+#pragma unroll
+            for (int i = 0; i < kCatPer; ++i) {
+                const int c = l + 32 * i;
+                if (c < C) {
+                    const float qv = expf(lq[i]), pv = expf(lp[i]);
+                    dql[base + c] = f * fq * (qv == 0.f ? 0.f : qv * (lq[i] - lp[i] - kl));
+                    dpl[base + c] = f * fp * (pv - qv);
+                }
+            }
+        }
+    }
+}
+
 static int finish(double* partials, int nb, float* scalars, int slot, hipStream_t s, const char* name) {
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, partials, nb, scalars, slot);
     BD_CHECK_LAUNCH(name);
@@ -332,6 +528,58 @@ int bd_polyak(float* target, const float* src, size_t n, float weight, void* str
     BD_REQUIRE(target && src && n > 0, "bd_polyak: bad arguments");
     hipLaunchKernelGGL(polyak_kernel, dim3(red_blocks(n)), dim3(256), 0, (hipStream_t)stream, target, src, n, weight);
     BD_CHECK_LAUNCH("bd_polyak");
+    return 0;
+}
+
+static inline int cat_blocks(size_t units) {
+    size_t b = (units + 7) / 8;
+    return (int)(b < 1 ? 1 : (b > (size_t)kRedBlocks ? (size_t)kRedBlocks : b));
+}
+
+int bd_categorical_head_forward(const float* logits, const float* q_noise, int rows, int D, int C, float* state,
+                                float* probs, void* stream) {
+    BD_REQUIRE(logits && q_noise && state && probs && rows > 0 && D > 0, "bd_categorical_head_forward: bad arguments");
+    BD_REQUIRE(C > 0 && C <= 32 * kCatPer, "bd_categorical_head_forward: %d classes (max %d)", C, 32 * kCatPer);
+    const size_t groups = (size_t)rows * D;
+    hipLaunchKernelGGL(cat_head_fwd_kernel, dim3(cat_blocks(groups)), dim3(256), 0, (hipStream_t)stream, logits, q_noise,
+                       groups, C, state, probs);
+    BD_CHECK_LAUNCH("bd_categorical_head_forward");
+    return 0;
+}
+
+int bd_categorical_head_backward(const float* dstate, const float* probs, int rows, int D, int C, float* dlogits,
+                                 void* stream) {
+    BD_REQUIRE(dstate && probs && dlogits && rows > 0 && D > 0, "bd_categorical_head_backward: bad arguments");
+    BD_REQUIRE(C > 0 && C <= 32 * kCatPer, "bd_categorical_head_backward: %d classes (max %d)", C, 32 * kCatPer);
+    const size_t groups = (size_t)rows * D;
+    hipLaunchKernelGGL(cat_head_bwd_kernel, dim3(cat_blocks(groups)), dim3(256), 0, (hipStream_t)stream, dstate, probs,
+                       groups, C, dlogits);
+    BD_CHECK_LAUNCH("bd_categorical_head_backward");
+    return 0;
+}
+
+int bd_kl_categorical_forward(const float* post_logits, const float* prior_logits, int rows, int D, int C, float free_nats,
+                              int sum_form, float* scalars, int slot, float* ws, void* stream) {
+    BD_REQUIRE(post_logits && prior_logits && scalars && ws && rows > 0 && D > 0, "bd_kl_categorical_forward: bad arguments");
+    BD_REQUIRE(C > 0 && C <= 32 * kCatPer, "bd_kl_categorical_forward: %d classes (max %d)", C, 32 * kCatPer);
+    const int nb = cat_blocks(sum_form ? (size_t)rows : (size_t)rows * D);
+    hipLaunchKernelGGL(cat_kl_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, post_logits, prior_logits, rows, D, C,
+                       free_nats, sum_form, (double*)ws);
+    BD_CHECK_LAUNCH("bd_kl_categorical_forward");
+    return finish((double*)ws, nb, scalars, slot, (hipStream_t)stream, "bd_kl_categorical_forward(final)");
+}
+
+int bd_kl_categorical_backward(const float* post_logits, const float* prior_logits, int rows, int D, int C, float free_nats,
+                               float kl_balance, float weight, float inv_count, const float* scalars, int slot,
+                               float* dpost, float* dprior, void* stream) {
+    BD_REQUIRE(post_logits && prior_logits && scalars && dpost && dprior && rows > 0 && D > 0,
+               "bd_kl_categorical_backward: bad arguments");
+    BD_REQUIRE(C > 0 && C <= 32 * kCatPer, "bd_kl_categorical_backward: %d classes (max %d)", C, 32 * kCatPer);
+    const bool sum_form = kl_balance == -1.f;
+    hipLaunchKernelGGL(cat_kl_bwd_kernel, dim3(cat_blocks(sum_form ? (size_t)rows : (size_t)rows * D)), dim3(256), 0,
+                       (hipStream_t)stream, post_logits, prior_logits, rows, D, C, free_nats, kl_balance, weight, inv_count,
+                       scalars, slot, dpost, dprior);
+    BD_CHECK_LAUNCH("bd_kl_categorical_backward");
     return 0;
 }
 

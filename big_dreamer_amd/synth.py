@@ -225,3 +225,24 @@ def make_planner_noise(d: Dims, B: int, horizon: int, iters: int, candidates: in
         for t in range(horizon):
             st[it, t] = ns.normal((B * candidates, d.S))
     return {"action": act, "state": st}
+
+
+# CategoricalBeliefModel cases (src/models.py:76-117): name -> (rows, input, hidden, D groups, C classes, seed)
+CATEGORICAL_CASES = {
+    "cat_small": (7, 24, 20, 4, 6, 21),
+    "cat_wide_classes": (5, 16, 12, 3, 40, 22),          # more classes than a half wave has lanes
+    "cat_reference": (16, 200, 200, 32, 32, 23),        # discrete_latent_dimensions x classes of conf/config.yaml
+}
+
+
+def make_categorical_case(rows: int, inp: int, hid: int, D: int, C: int, seed: int) -> Dict[str, np.ndarray]:
+    """Weights (PyTorch-default-like uniform init), input, output cotangents and a second set of logits for the KL.
+    (The Exp(1) sampling noise is drawn inside ATen by the reference run; the golden file stores it.)"""
+    rng = np.random.Generator(np.random.PCG64(seed + 7000))
+    u = lambda shape, k: rng.uniform(-1.0 / np.sqrt(k), 1.0 / np.sqrt(k), size=shape).astype(np.float32)
+    f = lambda *shape: rng.standard_normal(shape, dtype=np.float32)
+    return {"model.0.weight": u((hid, inp), inp), "model.0.bias": u((hid,), inp),
+            "model.2.weight": (3.0 * u((D * C, hid), hid)).astype(np.float32), "model.2.bias": u((D * C,), hid),
+            "x": f(rows, inp),
+            "g_state": f(rows, D * C), "g_logits": (0.1 * f(rows, D, C)).astype(np.float32),
+            "other_logits": (1.5 * f(rows, D, C)).astype(np.float32)}

@@ -310,6 +310,25 @@ int bd_lambda_return_forward(const float* reward, const float* value, int Hm, in
 int bd_lambda_return_backward(const float* dreturns, float dret_const, int Hm, int N, float discount,
                               float lambda_, float* dreward, float* dvalue, void* stream);
 
+/* ---- Categorical latents: CategoricalBeliefModel tail (src/models.py:108-117) and the Categorical branch of
+ * Dreamer._kl_loss (src/dreamer.py:102-106,131-144).  logits / state / probs are [rows x D*C], D groups of C classes.
+ * Forward: probs = softmax(logits) per group; state = one_hot(argmax(probs / q_noise)) with q_noise ~ Exp(1), which is
+ * torch.multinomial's single-draw algorithm behind OneHotCategoricalStraightThrough.rsample(); the straight-through
+ * term adds exactly zero.  Backward: dlogits = probs * (dstate - sum_c probs * dstate) per group. */
+int bd_categorical_head_forward(const float* logits, const float* q_noise, int rows, int D, int C, float* state,
+                                float* probs, void* stream);
+int bd_categorical_head_backward(const float* dstate, const float* probs, int rows, int D, int C, float* dlogits,
+                                 void* stream);
+/* KL(post || prior) between the D categorical factors.  Forward writes the RAW sum into scalars[slot] (sum over all
+ * rows*D groups; with sum_form -- kl_balance == -1 -- the sum over rows of max(sum_D KL, free_nats)); ws as for the
+ * other reductions.  Backward (same conventions as bd_kl_backward): balanced form lhs -> dprior, rhs -> dpost, both
+ * gated by the free-nats clamp of the mean scalars[slot] * inv_count. */
+int bd_kl_categorical_forward(const float* post_logits, const float* prior_logits, int rows, int D, int C, float free_nats,
+                              int sum_form, float* scalars, int slot, float* ws, void* stream);
+int bd_kl_categorical_backward(const float* post_logits, const float* prior_logits, int rows, int D, int C, float free_nats,
+                               float kl_balance, float weight, float inv_count, const float* scalars, int slot,
+                               float* dpost, float* dprior, void* stream);
+
 /* ---- CEM planner: MPCPlanner.forward (src/planner.py:28-90) -------------------------------------
  * One CEM iteration = bd_plan_rollout + bd_cem_refit.  rows = B * cand candidate action sequences (row = b * cand + c);
  * the rollout forms a_t = act_mean[t][b] + act_std[t][b] * eps_action[t][row] (src/planner.py:60-62), runs the

@@ -267,6 +267,48 @@ def adam_step(params, grads, st: AdamState, lr: float, eps: float, weight_decay:
 
 
 # ----------------------------------------------------------------------------------------------
+# R2c: Categorical latents -- CategoricalBeliefModel.forward and the Categorical KL branch
+# ----------------------------------------------------------------------------------------------
+def categorical_belief(inp: Tensor, sd: Dict[str, Tensor], q_noise: Tensor, D: int, C: int):
+    """CategoricalBeliefModel.forward (src/models.py:101-117): returns state (rows, D*C), (logits (rows, D, C),).
+
+    ``OneHotCategoricalStraightThrough(logits).rsample()`` = one_hot(sample) + probs - probs.detach() with
+    probs = softmax(logits - logsumexp(logits)); the sample is torch.multinomial(probs, 1, True), whose single-draw
+    path is ``q = empty_like(probs).exponential_(1); argmax(probs / q)`` -- ``q_noise`` (rows, D, C) are those draws."""
+    logits = F.linear(F.elu(F.linear(inp, sd["model.0.weight"], sd["model.0.bias"])), sd["model.2.weight"],
+                      sd["model.2.bias"])                                                   # :108
+    logits = logits.reshape(*logits.shape[:-1], D, C)                                       # :109-111
+    norm = logits - logits.logsumexp(dim=-1, keepdim=True)
+    probs = F.softmax(norm, dim=-1)
+    idx = (probs / q_noise).argmax(dim=-1)
+    sample = F.one_hot(idx, C).to(probs.dtype)
+    state = sample + (probs - probs.detach())                                               # :114-115
+    return state.reshape(*state.shape[:-2], D * C), (logits,)                               # :116-117
+
+
+def kl_categorical(q_logits: Tensor, p_logits: Tensor) -> Tensor:
+    """kl_divergence(OneHotCategorical(q), OneHotCategorical(p)) per factor (torch.distributions.kl
+    ``_kl_categorical_categorical``): sum_c q (log q - log p), with the library's 0 / inf conventions."""
+    lq = q_logits - q_logits.logsumexp(dim=-1, keepdim=True)
+    lp = p_logits - p_logits.logsumexp(dim=-1, keepdim=True)
+    qp, pp = F.softmax(lq, dim=-1), F.softmax(lp, dim=-1)
+    t = qp * (lq - lp)
+    t = torch.where(pp == 0, torch.full_like(t, float("inf")), t)
+    t = torch.where(qp == 0, torch.zeros_like(t), t)
+    return t.sum(-1)
+
+
+def kl_loss_categorical(post_logits: Tensor, prior_logits: Tensor, kl_balance: float, free_nats: float) -> Tensor:
+    """Dreamer._kl_loss, Categorical branch (src/dreamer.py:102-106,119-144); logits are (T, B, D, C)."""
+    fn = torch.full((1,), free_nats)
+    if kl_balance == -1:
+        return torch.max(kl_categorical(post_logits, prior_logits).sum(dim=2), fn).mean(dim=(0, 1))   # :122-128
+    lhs = kl_categorical(post_logits.detach(), prior_logits).mean()                          # :134
+    rhs = kl_categorical(post_logits, prior_logits.detach()).mean()                          # :135
+    return kl_balance * torch.max(lhs, fn) + (1 - kl_balance) * torch.max(rhs, fn)           # :140-144
+
+
+# ----------------------------------------------------------------------------------------------
 # MPCPlanner.forward (src/planner.py:28-90): cross-entropy method over prior-only rollouts
 # ----------------------------------------------------------------------------------------------
 def mpc_planner(P, belief: Tensor, state: Tensor, action_size: int, planning_horizon: int, optimisation_iters: int,

@@ -310,12 +310,65 @@ def run_planet(name: str, d: synth.Dims, seed: int):
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+def run_categorical(dreamer_mod):
+    """R2c pieces that are callable in the reference: CategoricalBeliefModel.forward
+    (src/models.py:101-117) with its autograd gradients, and Dreamer._kl_loss / _get_dist, Categorical branch
+    (src/dreamer.py:92-146), with gradients w.r.t. both logits."""
+    import models as ref_models
+    out = {}
+    for name, (rows, inp, hid, D, C, seed) in synth.CATEGORICAL_CASES.items():
+        c = synth.make_categorical_case(rows, inp, hid, D, C, seed)
+        m = ref_models.CategoricalBeliefModel(inp, hid, D, C, "ELU")
+        m.load_state_dict({k: torch.from_numpy(c[k].copy()) for k in ("model.0.weight", "model.0.bias", "model.2.weight",
+                                                                      "model.2.bias")})
+        x = torch.from_numpy(c["x"].copy()).requires_grad_(True)
+        # The sampling noise is drawn inside ATen (torch.multinomial's single-draw path: q ~ Exp(1) per class,
+        # argmax(probs / q)), out of reach of a Python patch: draw the same stream first, store it, re-seed, run.
+        torch.manual_seed(seed)
+        q = torch.empty(rows * D, C).exponential_(1)
+        torch.manual_seed(seed)
+        state, (logits,) = m(x)
+        with torch.no_grad():
+            pr = torch.softmax(logits - logits.logsumexp(-1, keepdim=True), -1).reshape(-1, C)
+            assert torch.equal((pr / q).argmax(-1), state.detach().reshape(-1, C).argmax(-1)), \
+                "the stored draws are not the ones the reference's sampler consumed"
+        out[f"{name}.q"] = q.numpy().reshape(rows, D, C).copy()
+        loss = (state * torch.from_numpy(c["g_state"])).sum() + (logits * torch.from_numpy(c["g_logits"])).sum()
+        loss.backward()
+        out[f"{name}.state"] = t2n(state)
+        out[f"{name}.logits"] = t2n(logits)
+        out[f"{name}.dx"] = t2n(x.grad)
+        for k, p in m.named_parameters():
+            store(out, f"{name}.grad.{k}", t2n(p.grad), full=p.numel() <= 20000)
+        # KL between these logits (posterior role) and a second set (prior role), every branch of _kl_loss
+        for tag, bal, fn in (("bal_clamped", 0.8, 3.0), ("bal_free", 0.8, 0.0), ("sum_mixed", -1, None)):
+            ql = logits.detach().reshape(1, rows, D, C).clone().requires_grad_(True)
+            pl = torch.from_numpy(c["other_logits"].copy()).reshape(1, rows, D, C).requires_grad_(True)
+            if fn is None:      # sum form: threshold BETWEEN the two middle rows, so both sides of the max occur
+                from torch.distributions import OneHotCategoricalStraightThrough as OH, kl_divergence
+                srt = kl_divergence(OH(logits=ql.detach()), OH(logits=pl.detach())).sum(dim=2).reshape(-1).sort().values
+                fn = float(0.5 * (srt[rows // 2 - 1] + srt[rows // 2]))
+            ns = types.SimpleNamespace(latent_distribution="Categorical", kl_balance=bal,
+                                       free_nats=torch.full((1,), fn))
+            ns._get_dist = types.MethodType(dreamer_mod.Dreamer._get_dist, ns)
+            kl = dreamer_mod.Dreamer._kl_loss(ns, (ql,), (pl,))
+            kl.sum().backward()
+            out[f"{name}.kl.{tag}"] = t2n(kl)
+            out[f"{name}.kl.{tag}.free_nats"] = np.array(fn, dtype=np.float64)
+            out[f"{name}.kl.{tag}.dpost"] = t2n(ql.grad)
+            out[f"{name}.kl.{tag}.dprior"] = t2n(pl.grad)
+    path = os.path.join(ROOT, "tests", "golden", "categorical.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
 def main_planner(dreamer_mod):
     run_planner(dreamer_mod, "planner_tiny", synth.TINY, B=2, horizon=5, iters=4, candidates=64, top=8, seed=6, full=True)
     # the reference's defaults (conf/config.yaml:31,63-66) at the config-2 model size, one environment
     run_planner(dreamer_mod, "planner_config2", synth.CONFIG2, B=1, horizon=15, iters=10, candidates=1000, top=100,
                 seed=7, full=False)
     run_planet("tiny_planet", synth.TINY, seed=8)
+    run_categorical(dreamer_mod)
 
 
 def main():

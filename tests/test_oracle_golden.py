@@ -133,3 +133,32 @@ def test_planet_train_steps_against_reference():
                 assert_close(f"step{step}.param.{mod}.{k}", p.detach().numpy(), g[f"step{step}.param.{mod}.{k}"],
                              2e-6, 1e-5)
                 i += 1
+
+
+@pytest.mark.parametrize("name", list(synth.CATEGORICAL_CASES))
+def test_categorical_latents_against_reference(name):
+    """R2c, the pieces the reference can run: CategoricalBeliefModel.forward
+    (src/models.py:101-117) -- sampled one-hot states bit-exact, logits and autograd gradients to fp32 rounding -- and
+    the Categorical branch of Dreamer._kl_loss (src/dreamer.py:102-146) with gradients, in all three regimes
+    (balanced + clamped, balanced + free, summed with the free-nats threshold between the two middle rows)."""
+    rows, inp, hid, D, C, seed = synth.CATEGORICAL_CASES[name]
+    g = load_golden("categorical")
+    c = synth.make_categorical_case(rows, inp, hid, D, C, seed)
+    sd = {k: torch.tensor(c[k], requires_grad=True) for k in ("model.0.weight", "model.0.bias", "model.2.weight",
+                                                              "model.2.bias")}
+    x = torch.tensor(c["x"], requires_grad=True)
+    state, (logits,) = O.categorical_belief(x, sd, torch.as_tensor(g[f"{name}.q"]), D, C)
+    assert np.array_equal(state.detach().numpy(), g[f"{name}.state"]), "sampled one-hot states differ"
+    assert_close("logits", logits.detach().numpy(), g[f"{name}.logits"], 2e-6, 1e-5)
+    ((state * torch.as_tensor(c["g_state"])).sum() + (logits * torch.as_tensor(c["g_logits"])).sum()).backward()
+    assert_close("dx", x.grad.numpy(), g[f"{name}.dx"], 2e-6, 1e-4)
+    for k, p in sd.items():
+        compare_tensor(g, f"{name}.grad.{k}", p.grad.numpy(), p.numel() <= 20000, 2e-6, 1e-4)
+    for tag, bal in (("bal_clamped", 0.8), ("bal_free", 0.8), ("sum_mixed", -1)):
+        ql = torch.tensor(g[f"{name}.logits"]).reshape(1, rows, D, C).requires_grad_(True)
+        pl = torch.tensor(c["other_logits"]).reshape(1, rows, D, C).requires_grad_(True)
+        kl = O.kl_loss_categorical(ql, pl, bal, float(g[f"{name}.kl.{tag}.free_nats"]))
+        kl.sum().backward()
+        assert_close(f"kl.{tag}", kl.detach().numpy(), g[f"{name}.kl.{tag}"], 1e-6, 1e-5)
+        assert_close(f"kl.{tag}.dpost", ql.grad.numpy(), g[f"{name}.kl.{tag}.dpost"], 1e-7, 1e-4)
+        assert_close(f"kl.{tag}.dprior", pl.grad.numpy(), g[f"{name}.kl.{tag}.dprior"], 1e-7, 1e-4)
