@@ -116,9 +116,12 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or os.environ.get("BD_FORCE_DP", "0") == "1"    # BD_FORCE_DP=1: one-rank rehearsal of the RCCL path
+    if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from big_dreamer_amd import synth
     from big_dreamer_amd.engine import DreamerEngine
@@ -158,7 +161,7 @@ def main():
 
     def fence():
         eng.join()          # everything queued on the engine's streams, incl. optimiser steps it issues one step late
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -170,7 +173,7 @@ def main():
     dt = time.perf_counter() - t0
     log(f"timed {args.steps} steps in {dt * 1e3:.1f} ms")
     logs = eng.logs()
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -216,7 +219,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -194,7 +194,18 @@ class DreamerEngine:
         # data-parallel: actor / critic optimiser steps (their all-reduces) are issued one host step late, see
         # _optimizer_step_or_defer; BD_DEFER_OPT=1 forces the same order on one GPU (tests)
         self.defer_opt = world_size > 1 or os.environ.get("BD_DEFER_OPT", "0") == "1"
+        if os.environ.get("BD_FORCE_DP", "0") == "1" and torch.distributed.is_initialized():
+            self.dp.force = self.defer_opt = True      # single-rank rehearsal of the data-parallel schedule
+        if (world_size > 1 or self.dp.force) and torch.cuda.current_stream(self.dev) == torch.cuda.default_stream(self.dev):
+            # The legacy null stream synchronises implicitly with every BLOCKING stream of the process, and RCCL's is
+            # one: with collectives in flight, each replay gather / stream hand-over the caller issues on the null
+            # stream waits for the communicator to drain, i.e. for behaviour learning of the previous step -- the
+            # cross-step pipeline collapses to the serial schedule (measured with a one-rank communicator: 3.47 ->
+            # 5.33 ms/step).  Data-parallel runs therefore move the calling thread to a non-blocking stream.
+            self._main_stream = torch.cuda.Stream(self.dev)
+            torch.cuda.set_stream(self._main_stream)
         self._pending_opt: List[tuple] = []
+        self._wm_done_hist: List[torch.cuda.Event] = []
         self._parity = 0
         self._wgrad_ws_bh = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.red_ws_bh = torch.zeros(int(lib.bd_reduce_ws_floats()), dtype=torch.float32, device=self.dev)
@@ -714,6 +725,14 @@ class DreamerEngine:
             feat = self._dynamics_phase(batch, nz, f"p{par}_")
             ev_wm_done = torch.cuda.Event()
             ev_wm_done.record(s_wm)
+        # A caller that does not wait for the logs runs many steps ahead of the GPU, and its sampler recycles a small ring
+        # of batch buffers (ExperienceReplay._out: 4 deep): order whatever the caller enqueues next on ITS stream behind
+        # dynamics learning of two steps ago, so that a gather can never overwrite a batch that has not been consumed.
+        self._wm_done_hist.append(ev_wm_done)
+        if len(self._wm_done_hist) > 2:
+            ev_old = self._wm_done_hist.pop(0)
+            if os.environ.get("BD_BATCH_GUARD", "1") != "0":      # "0": diagnosis only (tests show the race without it)
+                cur.wait_event(ev_old)
         self._flush_pending_opt()                   # actor / critic updates of the previous step (data-parallel runs)
         with torch.cuda.stream(s_bh):
             s_bh.wait_event(ev_wm_done)

@@ -28,6 +28,9 @@ class DataParallel:
         assert world_size >= 1 and 0 <= rank < world_size
         self.world_size, self.rank, self.pg = world_size, rank, process_group
         self.groups = dict(groups or {})
+        # Rehearsal on one GPU: issue the collectives even with a single rank (a sum over one rank is the identity), so the
+        # stream ordering around the RCCL calls can be checked where only one device is at hand (BD_FORCE_DP=1).
+        self.force = False
 
     @staticmethod
     def make_phase_groups(backend: Optional[str] = None) -> dict:
@@ -41,7 +44,7 @@ class DataParallel:
 
     # ---- collectives -----------------------------------------------------------------------------------
     def allreduce_sum_(self, t: torch.Tensor, key: Optional[str] = None) -> torch.Tensor:
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force:
             pg = self.groups.get(key, self.pg)
             if t.is_cuda and torch.distributed.get_backend(pg) == "gloo":
                 # test transport only (several ranks sharing one GPU): stage through the host

@@ -190,6 +190,39 @@ def test_pipelined_schedule_is_bit_identical_to_serial(name):
     assert np.isfinite(list(logs[0].values())).all()
 
 
+def test_run_ahead_caller_trains_on_the_batches_it_sampled():
+    """A caller that never waits for the logs enqueues a step in ~1 ms while the GPU needs ~3.4 ms, so it is soon many
+    steps ahead; ExperienceReplay hands out batches from a ring of four buffers.  The engine must order the caller's
+    next gathers behind the dynamics phase that still has to read a recycled buffer: 14 un-synchronised pipelined steps
+    from the device replay end in exactly the weights of the serial schedule (same sampled indices, same device noise
+    stream).  (Regression: without that ordering the pipelined run consumed overwritten batches.)"""
+    from big_dreamer_amd.engine import DreamerEngine
+    from big_dreamer_amd.memory import ExperienceReplay
+    d = synth.CONFIG2
+    P = synth.make_params(d, 0)
+    rep = synth.make_replay(d, rows=2000, seed=0)
+    flats = []
+    for pipe in (True, False):
+        eng = DreamerEngine(d, None, "cuda", params=P)
+        eng.pipeline = pipe
+        buf = ExperienceReplay(2000, d.A, 5, False, d.O, torch.device("cuda"))
+        for k, v in rep.items():
+            getattr(buf, k)[:] = v
+        buf.idx, buf.full = 0, True
+        buf.sync_device()
+        np.random.seed(5)
+        torch.manual_seed(5)
+        torch.cuda.synchronize()
+        for _ in range(14):
+            o, a, r, n = buf.sample(d.B, d.L)
+            eng.train_step({"observations": o, "actions": a, "rewards": r, "nonterminals": n}, None, sync_logs=False)
+        eng.join()
+        torch.cuda.synchronize()
+        flats.append({g: eng.groups[g].flat.clone() for g in ("model", "actor", "critic")})
+    for g in ("model", "actor", "critic"):
+        assert torch.equal(flats[0][g], flats[1][g]), g
+
+
 def test_replay_sample_on_device_matches_reference_golden():
     """R0 through bd_replay_gather: same draws -> the reference's batches (bit exact, pure copies)."""
     from big_dreamer_amd.memory import ExperienceReplay

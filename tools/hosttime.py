@@ -30,6 +30,10 @@ def main():
     from big_dreamer_amd.memory import ExperienceReplay
     d = synth.CONFIG2
     dev = torch.device("cuda", 0)
+    if os.environ.get("BD_FORCE_DP", "0") == "1":      # one-rank rehearsal of the data-parallel schedule over RCCL
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29519")
+        torch.distributed.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
     eng = DreamerEngine(d, None, dev, params=synth.make_params(d, 0))
     rep = synth.make_replay(d, rows=5000, seed=0)
     buf = ExperienceReplay(5000, d.A, 5, False, d.O, dev)
@@ -42,6 +46,10 @@ def main():
         o, a, r, n = buf.sample(d.B, d.L)
         eng.train_step({"observations": o, "actions": a, "rewards": r, "nonterminals": n}, None, sync_logs=False)
 
+    if os.environ.get("BD_MAIN_STREAM", "1") == "0":
+        # diagnosis: put the caller back on the legacy null stream (the engine moves a data-parallel caller off it: the
+        # null stream synchronises implicitly with RCCL's blocking stream and serialises the pipeline)
+        torch.cuda.set_stream(torch.cuda.default_stream())
     for _ in range(5):
         step()
     torch.cuda.synchronize()
