@@ -167,11 +167,26 @@ class Dreamer:
     def get_action(self, belief: Tensor, state: Tensor, deterministic: bool = False,
                    _noise: Optional[Dict[str, Tensor]] = None) -> Tuple[Tensor, Tensor]:
         """src/dreamer.py:429-444: tanh-Normal sample and its 100-sample entropy estimate."""
-        if deterministic:
-            raise NotImplementedError("deterministic=True (SampleDist.mode) is never used by the reference loop")
         e, d = self.engine, self.dims
         e.join()
         N = belief.shape[0]
+        if deterministic:
+            # SampleDist.mode (src/models.py:709-723): of n_samples draws, the one with the highest log-density per row;
+            # then the entropy estimate on fresh draws (RNG order: mode, entropy).  Never used by the reference loop --
+            # a few elementwise torch ops on the actor's (mean, std), entropy from the same kernel as below.
+            mean, std = self.actor(belief, state)
+            nz = _noise or {}
+            eps = nz["mode"].to(e.dev).float() if "mode" in nz else torch.randn(d.n_entropy, N, d.A, device=e.dev)
+            sample = torch.tanh(mean.unsqueeze(0) + std.unsqueeze(0) * eps)
+            idx = torch.argmax(_tanh_normal_log_prob(sample, mean.unsqueeze(0), std.unsqueeze(0)), dim=0)
+            action = torch.gather(sample, 0, idx.reshape(1, N, 1).expand(1, N, d.A)).squeeze(0)
+            start = torch.cat([belief, state], dim=1).contiguous().float()
+            noise = {"action": torch.zeros(1, N, d.A, device=e.dev),
+                     "entropy": (nz["entropy"].to(e.dev).float().reshape(1, d.n_entropy, N, d.A) if "entropy" in nz
+                                 else torch.randn(1, d.n_entropy, N, d.A, device=e.dev)),
+                     "img_prior": torch.zeros(1, N, d.S, device=e.dev)}
+            _, ent, _ = e.imagine(start, N, 1, noise, save=False, tag="act_")
+            return action, ent.view(N).clone()
         start = torch.cat([belief, state], dim=1).contiguous().float()
         noise = _noise or {"action": torch.randn(1, N, d.A, device=e.dev),
                            "entropy": torch.randn(1, d.n_entropy, N, d.A, device=e.dev),
@@ -204,6 +219,16 @@ class DreamerV2(Dreamer):
             p["kl_loss_weight"] = 0.1
         super().__init__(p, env, **kw)
         self.kl_balance = p["kl_balance"]
+
+
+def _tanh_normal_log_prob(y: Tensor, mean: Tensor, std: Tensor) -> Tensor:
+    """Independent(TransformedDistribution(Normal(mean, std), TanhBijector()), 1).log_prob(y) (src/models.py:630-673)."""
+    import math
+    yc = torch.where(torch.abs(y) <= 1.0, torch.clamp(y, -0.99999997, 0.99999997), y)
+    x = 0.5 * torch.log((1 + yc) / (1 - yc))
+    ladj = 2.0 * (math.log(2) - x - torch.nn.functional.softplus(-2.0 * x))
+    base = -((x - mean) ** 2) / (2 * std ** 2) - torch.log(std) - math.log(math.sqrt(2 * math.pi))
+    return (base - ladj).sum(-1)
 
 
 def lambda_return(imged_reward: Tensor, value_pred: Tensor, bootstrap: Tensor, discount: float = 0.99,

@@ -150,7 +150,41 @@ class ActorModel(_EngineBacked):
         self._min_std, self._init_std, self._mean_scale = min_std, init_std, mean_scale
         self.raw_init_std = torch.log(torch.exp(torch.tensor(float(init_std))) - 1)
         self.action_distribution = action_distribution
+        self._sizes = (belief_size + state_size, hidden_size, 2 * action_size)
         self._bind(engine, "actor", "actor")
+
+    @torch.no_grad()
+    def forward(self, belief: Tensor, state: Tensor) -> Tuple[Tensor, Tensor]:
+        """src/models.py:506-517: (action_mean, action_std) = (5 tanh(m / 5), softplus(r + raw_init_std) + min_std).
+        Inference entry point (the training step runs the actor inside the imagination kernels): the dense chain runs
+        on bd_mlp_forward with the weights packed per call."""
+        from . import _cabi as cabi
+        from .categorical import _pack
+        import ctypes as C
+        self._eng.join()      # order after any queued pipeline work (engine.train_step)
+        F, Hd, out = self._sizes
+        lead = belief.shape[:-1]
+        x = torch.cat([belief, state], dim=-1).reshape(-1, F).contiguous().float()
+        M = x.shape[0]
+        res = torch.empty(M, out, dtype=torch.float32, device=x.device)
+        a = cabi.MlpFwdArgs()
+        a.M, a.in0, a.ld0, a.w0 = M, x.data_ptr(), F, F
+        a.in1, a.ld1, a.w1 = None, 0, 0
+        a.n_layers = DENSE_LAYERS + 1
+        keep, k = [], F
+        for l in range(DENSE_LAYERS + 1):
+            lin = self.model[2 * l]
+            n = out if l == DENSE_LAYERS else Hd
+            keep.append(_pack(lin.weight, False))
+            a.layer[l] = cabi.Layer(keep[-1].data_ptr(), lin.bias.data_ptr(), n, k,
+                                    cabi.ACT_NONE if l == DENSE_LAYERS else cabi.ACT_ELU, None)
+            k = n
+        a.out, a.ldo = res.data_ptr(), out
+        cabi.check(cabi.lib.bd_mlp_forward(C.byref(a), cabi.stream()))
+        m, r = torch.chunk(res, 2, dim=1)
+        mean = self._mean_scale * torch.tanh(m / self._mean_scale)
+        std = torch.nn.functional.softplus(r + self.raw_init_std.to(r.device)) + self._min_std
+        return mean.view(*lead, -1), std.view(*lead, -1)
 
 
 class CnnImageEncoder(_EngineBacked):

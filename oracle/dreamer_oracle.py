@@ -165,6 +165,20 @@ def get_action(belief: Tensor, state: Tensor, sd: Dict[str, Tensor], eps_action:
     return action, -torch.mean(logp, 0)
 
 
+def get_action_mode(belief: Tensor, state: Tensor, sd: Dict[str, Tensor], eps_mode: Tensor,
+                    eps_entropy: Tensor) -> Tuple[Tensor, Tensor]:
+    """Dreamer.get_action(deterministic=True) (src/dreamer.py:440-444): SampleDist.mode (src/models.py:709-723) -- of
+    n_samples draws the one with the highest log-density per row -- then SampleDist.entropy on fresh draws.
+    eps_mode, eps_entropy (n_samples, N, A), consumed in that order."""
+    mean, std = actor_forward(belief, state, sd)
+    sample = torch.tanh(mean.unsqueeze(0) + std.unsqueeze(0) * eps_mode)                  # :713-714
+    logprob = tanh_normal_log_prob(sample, mean.unsqueeze(0), std.unsqueeze(0))           # :715
+    idx = torch.argmax(logprob, dim=0).reshape(1, -1, 1).expand(1, sample.size(1), sample.size(2))   # :718-722
+    action = torch.gather(sample, 0, idx).squeeze(0)                                      # :723
+    y = torch.tanh(mean.unsqueeze(0) + std.unsqueeze(0) * eps_entropy)
+    return action, -torch.mean(tanh_normal_log_prob(y, mean.unsqueeze(0), std.unsqueeze(0)), 0)
+
+
 # ----------------------------------------------------------------------------------------------
 # R4: imagine_ahead (src/dreamer.py:179-237)
 # ----------------------------------------------------------------------------------------------

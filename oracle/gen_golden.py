@@ -362,6 +362,26 @@ def run_categorical(dreamer_mod):
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+def run_action_mode(dreamer_mod, d: synth.Dims, seed: int):
+    """ActorModel.forward (src/models.py:506-517) and Dreamer.get_action(deterministic=True) (src/dreamer.py:429-444)."""
+    P = synth.make_params(d, seed)
+    agent = build_agent(dreamer_mod, d, P)
+    rng = np.random.Generator(np.random.PCG64(seed + 900))
+    N = 9
+    belief = (0.5 * rng.standard_normal((N, d.Be), dtype=np.float32)).astype(np.float32)
+    state = rng.standard_normal((N, d.S), dtype=np.float32)
+    ns = synth.NoiseStream(seed)
+    with torch.no_grad(), Inject(ns):
+        mean, std = agent.actor(torch.from_numpy(belief), torch.from_numpy(state))
+        action, entropy = agent.get_action(torch.from_numpy(belief), torch.from_numpy(state), deterministic=True)
+    assert ns.calls == [(d.n_entropy, N, d.A), (d.n_entropy, N, d.A)], ns.calls
+    out = {"belief": belief, "state": state, "mean": t2n(mean), "std": t2n(std), "action": t2n(action),
+           "entropy": t2n(entropy)}
+    path = os.path.join(ROOT, "tests", "golden", "action_mode.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}")
+
+
 def main_planner(dreamer_mod):
     run_planner(dreamer_mod, "planner_tiny", synth.TINY, B=2, horizon=5, iters=4, candidates=64, top=8, seed=6, full=True)
     # the reference's defaults (conf/config.yaml:31,63-66) at the config-2 model size, one environment
@@ -369,6 +389,7 @@ def main_planner(dreamer_mod):
                 seed=7, full=False)
     run_planet("tiny_planet", synth.TINY, seed=8)
     run_categorical(dreamer_mod)
+    run_action_mode(dreamer_mod, synth.SMALL, seed=12)
 
 
 def main():

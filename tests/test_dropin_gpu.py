@@ -157,3 +157,25 @@ def test_pixel_agent_surface():
     assert out[0].shape == (1, d.Be) and out[2].shape == (1, d.A)
     img = agent.observation_model(out[0], out[1])
     assert tuple(img.shape) == (1, 3, 64, 64)
+
+
+def test_actor_forward_and_deterministic_get_action_match_reference_golden():
+    """ActorModel.forward -> (mean, std) and Dreamer.get_action(deterministic=True) (SampleDist.mode, then the entropy
+    estimate) on the reference's draws; golden from the reference itself (tests/golden/action_mode.npz)."""
+    from tests.helpers import load_golden
+    d, seed = synth.SMALL, 12
+    g = load_golden("action_mode")
+    agent, P, env = _agent(d, seed)
+    N = g["belief"].shape[0]
+    ns = synth.NoiseStream(seed)
+    eps_mode, eps_ent = ns.normal((d.n_entropy, N, d.A)), ns.normal((d.n_entropy, N, d.A))
+    b, s = torch.from_numpy(g["belief"]).cuda(), torch.from_numpy(g["state"]).cuda()
+    mean, std = agent.actor(b, s)
+    assert_close("mean", mean.cpu().numpy(), g["mean"], 2e-5, 2e-5)
+    assert_close("std", std.cpu().numpy(), g["std"], 2e-5, 2e-5)
+    act, ent = agent.get_action(b, s, deterministic=True,
+                                _noise={"mode": torch.from_numpy(eps_mode), "entropy": torch.from_numpy(eps_ent)})
+    assert_close("action", act.cpu().numpy(), g["action"], 2e-5, 2e-5)
+    assert_close("entropy", ent.cpu().numpy(), g["entropy"], 2e-2, 1e-3)      # tolerance of the other entropy checks
+    act2, ent2 = agent.get_action(b, s, deterministic=True)                     # device noise
+    assert act2.shape == (N, d.A) and float(act2.abs().max()) <= 1.0 and torch.isfinite(ent2).all()

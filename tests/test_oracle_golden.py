@@ -162,3 +162,22 @@ def test_categorical_latents_against_reference(name):
         assert_close(f"kl.{tag}", kl.detach().numpy(), g[f"{name}.kl.{tag}"], 1e-6, 1e-5)
         assert_close(f"kl.{tag}.dpost", ql.grad.numpy(), g[f"{name}.kl.{tag}.dpost"], 1e-7, 1e-4)
         assert_close(f"kl.{tag}.dprior", pl.grad.numpy(), g[f"{name}.kl.{tag}.dprior"], 1e-7, 1e-4)
+
+
+def test_actor_forward_and_deterministic_action_against_reference():
+    """ActorModel.forward (src/models.py:506-517) and Dreamer.get_action(deterministic=True) -> SampleDist.mode
+    (src/dreamer.py:440-444, src/models.py:709-723) with the reference's draws (mode first, then entropy)."""
+    d, seed = synth.SMALL, 12
+    g = load_golden("action_mode")
+    P = {k: torch.as_tensor(v) for k, v in synth.make_params(d, seed)["actor"].items()}
+    N = g["belief"].shape[0]
+    ns = synth.NoiseStream(seed)
+    eps_mode, eps_ent = ns.normal((d.n_entropy, N, d.A)), ns.normal((d.n_entropy, N, d.A))
+    with torch.no_grad():
+        mean, std = O.actor_forward(torch.as_tensor(g["belief"]), torch.as_tensor(g["state"]), P)
+        act, ent = O.get_action_mode(torch.as_tensor(g["belief"]), torch.as_tensor(g["state"]), P,
+                                     torch.as_tensor(eps_mode), torch.as_tensor(eps_ent))
+    assert_close("mean", mean.numpy(), g["mean"], 1e-6, 1e-5)
+    assert_close("std", std.numpy(), g["std"], 1e-6, 1e-5)
+    assert_close("action", act.numpy(), g["action"], 1e-6, 1e-5)
+    assert_close("entropy", ent.numpy(), g["entropy"], 2e-5, 2e-5)
