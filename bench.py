@@ -127,6 +127,9 @@ def main():
     from big_dreamer_amd.engine import DreamerEngine
     from big_dreamer_amd.memory import ExperienceReplay
 
+    # Drive the engine from a non-blocking stream rather than the legacy null stream, which synchronises implicitly with
+    # every blocking stream of the process; the fences below are device-wide synchronisations.
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
     d = synth.CONFIG3 if args.pixel else synth.CONFIG2
     np.random.seed(rank)
     torch.manual_seed(rank)

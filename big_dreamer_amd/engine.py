@@ -170,8 +170,9 @@ class DreamerEngine:
         # head-chain and wgrad kernels already fill the chip and slow imagine_bwd down by contention), so it is off
         # by default (BD_OVERLAP_CRITIC=1 enables it; parity-tested either way).
         self.overlap_critic = os.environ.get("BD_OVERLAP_CRITIC", "0") == "1"
-        self._side = torch.cuda.Stream(device=self.dev)
-        self._s_early = torch.cuda.Stream(device=self.dev)      # pixel mode: decoder weight gradients under the observe scan
+        self._side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("BD_SIDE_PRIO", "0")))
+        # pixel mode: decoder weight gradients under the observe scan
+        self._s_early = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("BD_EARLY_PRIO", "0")))
         # Cross-step software pipeline (on unless BD_PIPELINE=0).  Dynamics learning of step k+1 reads only the world
         # model that step k's model optimiser wrote, never what step k's behaviour learning (imagination, actor,
         # critic) produces, while behaviour learning k needs the world model k and the posteriors k.  So the two
@@ -187,7 +188,10 @@ class DreamerEngine:
         # the critic update) are double-buffered by step parity.
         self.pipeline = os.environ.get("BD_PIPELINE", "1") != "0"
         self._s_wm = torch.cuda.Stream(device=self.dev, priority=-1)   # the scan is latency-bound: dispatch it first
-        self._s_bh = torch.cuda.Stream(device=self.dev, priority=-1)   # the actor chain bounds the step; critic: _side
+        # state observations: the actor chain bounds the step; pixels: the conv-heavy dynamics chain does, and behaviour
+        # learning should only fill its gaps (BD_BH_PRIO overrides: -1 high, 0 normal)
+        bh_prio = int(os.environ.get("BD_BH_PRIO", "0" if self.pixel else "-1"))
+        self._s_bh = torch.cuda.Stream(device=self.dev, priority=bh_prio)      # critic: _side
         self._ev_bh_wm_free: Optional[torch.cuda.Event] = None
         self._ev_bh_done: List[Optional[torch.cuda.Event]] = [None, None]
         self._ev_cr_done: List[Optional[torch.cuda.Event]] = [None, None]

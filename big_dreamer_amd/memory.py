@@ -31,6 +31,7 @@ class ExperienceReplay:
         self._dev = None          # device mirror, created lazily / refreshed by sync_device()
         self._dirty = True
         self._out_ring, self._out_i = {}, {}
+        self._pix_noise = None
         self._ring = []           # pinned staging buffers for the index upload (async H2D, no host stall)
         self._ring_i = 0
 
@@ -118,8 +119,12 @@ class ExperienceReplay:
         if self.pixel_observation:
             src = self._dev["observations"]
             pixels = 3 * 64 * 64
-            noise = torch.rand(L * n * pixels, dtype=torch.float32, device=self.device)     # rand_like, src/utils.py:317
-            dst = torch.empty(L * n * pixels, dtype=torch.float32, device=self.device)
+            # persistent buffers (no allocator traffic per step): the noise is consumed by the gather right behind it on
+            # the same stream; the batch comes from the same ring of four as the other arrays
+            if self._pix_noise is None or self._pix_noise.numel() != L * n * pixels:
+                self._pix_noise = torch.empty(L * n * pixels, dtype=torch.float32, device=self.device)
+            noise = self._pix_noise.uniform_()                                              # rand_like, src/utils.py:317
+            dst = self._out("pixels", L * n * pixels)
             cabi.check(cabi.lib.bd_replay_gather_pixels(src.data_ptr(), vidx.data_ptr(), L * n, pixels, self.bit_depth,
                                                         noise.data_ptr(), dst.data_ptr(), cabi.stream()))
             out.append(dst.view(L, n, 3, 64, 64))

@@ -30,6 +30,7 @@ def my_app(argv):
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
     if world > 1:
         torch.distributed.init_process_group("nccl")
+    torch.cuda.set_stream(torch.cuda.Stream())        # stay off the legacy null stream
     from big_dreamer_amd.dreamer import Dreamer, DreamerV2
     from big_dreamer_amd.planet import Planet
     from big_dreamer_amd.env import Env
