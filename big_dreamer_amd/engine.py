@@ -187,7 +187,7 @@ class DreamerEngine:
         # `feat` (posterior features, read by behaviour learning), the imagined features and the lambda-returns (read by
         # the critic update) are double-buffered by step parity.
         self.pipeline = os.environ.get("BD_PIPELINE", "1") != "0"
-        self._s_wm = torch.cuda.Stream(device=self.dev, priority=-1)   # the scan is latency-bound: dispatch it first
+        self._s_wm = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("BD_WM_PRIO", "-1")))   # the scan is latency-bound: dispatch it first
         # state observations: the actor chain bounds the step; pixels: the conv-heavy dynamics chain does, and behaviour
         # learning should only fill its gaps (BD_BH_PRIO overrides: -1 high, 0 normal)
         bh_prio = int(os.environ.get("BD_BH_PRIO", "0" if self.pixel else "-1"))
