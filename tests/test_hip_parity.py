@@ -152,6 +152,43 @@ def test_train_steps_vs_oracle_and_golden(name, cluster, monkeypatch):
         print("\n".join(rep[-400:]))
 
 
+def test_wide_batch_uses_two_column_blocks_per_cluster_member():
+    """B = 320 sequences = 20 row tiles: 20 x 13 single-block members would not be co-resident on 256 CUs, so the observe
+    scans run with 7 members per tile owning two GRU column blocks each (observe_cluster.hip, pick_cluster).  One whole
+    train step at the config-2 model size against the oracle (no golden file at this batch size)."""
+    from big_dreamer_amd import _cabi as cabi
+    from big_dreamer_amd.engine import DreamerEngine
+    from oracle import dreamer_oracle as O
+    d = synth.Dims(B=320, L=5, H=3)
+    assert int(cabi.lib.bd_observe_cluster_size(d.B, d.Be)) == 7
+    P = synth.make_params(d, 31)
+    batch, nz = synth.make_batch(d, 31), synth.make_noise(d, 31)
+    od = O.OracleDreamer(P, dict(planning_horizon=d.H, free_nats=0.5))
+    eng = DreamerEngine(d, dict(free_nats=0.5), "cuda", params=P)
+    assert eng._cluster_ok(d.B)
+    ologs = od.train_step(batch, nz)
+    logs = eng.train_step(_dev(batch), _dev(nz))
+    torch.cuda.synchronize()
+    eng.cluster_status(d.B)
+    rep = []
+    try:
+        for k, v in ologs.items():
+            tol = (2e-4, 2e-4) if k in ("policy_entropy", "actor_loss") else (2e-5, 5e-5)
+            _rel(k, logs[k], v, tol[0], tol[1], rep)
+        gn = od.last["grad_norms"]
+        coef = min(1.0, od.hp["grad_clip_norm"] / (gn["model"] + 1e-6))
+        i = 0
+        for mod in O.MODEL_MODULES:
+            for k, p in od.P[mod].items():
+                want = od.last["model_grads"][i].numpy() * coef
+                scale = float(np.abs(want).max()) + 1e-12
+                _rel(f"grad.{mod}.{k}", eng.G(mod, k).cpu().numpy(), want, 2e-3 * scale + 1e-9, 2e-3, rep)
+                _rel(f"param.{mod}.{k}", eng.W(mod, k).cpu().numpy(), p.detach().numpy(), 2e-5, 1e-5, rep)
+                i += 1
+    finally:
+        print("\n".join(rep[-60:]))
+
+
 @pytest.mark.parametrize("name", ["small", "config2"])
 def test_pipelined_schedule_is_bit_identical_to_serial(name):
     """Cross-step pipeline (dynamics learning of step k+1 under behaviour learning of step k on two HIP streams,
