@@ -152,6 +152,47 @@ def test_train_steps_vs_oracle_and_golden(name, cluster, monkeypatch):
         print("\n".join(rep[-400:]))
 
 
+@pytest.mark.parametrize("dims", [synth.Dims(B=5, L=4, H=4, Be=40, S=10, Hd=32, E=64, A=17, O=6),      # HumanoidStandup's action width
+                                  synth.Dims(B=18, L=3, H=3, Be=200, S=30, Hd=200, E=1024, A=17, O=3)])
+def test_wide_action_vectors_vs_oracle(dims):
+    """A = 17 (configs[2-3]) needs two K blocks for the action operand and two column blocks for the actor's mean / std
+    heads; the golden cases stop at A = 3.  Two train steps against the oracle."""
+    from big_dreamer_amd.engine import DreamerEngine
+    from oracle import dreamer_oracle as O
+    d = dims
+    P = synth.make_params(d, 41)
+    od = O.OracleDreamer(P, dict(planning_horizon=d.H))
+    eng = DreamerEngine(d, None, "cuda", params=P)
+    batch = synth.make_batch(d, 41)
+    rep = []
+    try:
+        for step in range(2):
+            nz = synth.make_noise(d, 41 + step)
+            ologs = od.train_step(batch, nz)
+            logs = eng.train_step(_dev(batch), _dev(nz))
+            torch.cuda.synchronize()
+            for k, v in ologs.items():
+                tol = (5e-4, 5e-4) if k in ("policy_entropy", "actor_loss") else (2e-5, 5e-5)
+                _rel(f"s{step}.{k}", logs[k], v, tol[0], tol[1], rep)
+            gn = od.last["grad_norms"]
+            coef = {k: min(1.0, od.hp["grad_clip_norm"] / (gn[k] + 1e-6)) for k in gn}
+            groups = {"model": (O.MODEL_MODULES, od.last["model_grads"]), "actor": (("actor",), od.last["actor_grads"]),
+                      "critic": (("critic",), od.last["critic_grads"])}
+            for grp, (mods, grads) in groups.items():
+                i = 0
+                for mod in mods:
+                    for k in od.P[mod]:
+                        want = grads[i].numpy() * coef[grp]
+                        scale = float(np.abs(want).max()) + 1e-12
+                        _rel(f"s{step}.grad.{mod}.{k}", eng.G(mod, k).cpu().numpy(), want, 2e-3 * scale + 1e-9, 2e-3, rep)
+                        i += 1
+            for mod in list(O.MODEL_MODULES) + ["actor", "critic"]:
+                for k, p in od.P[mod].items():
+                    _rel(f"s{step}.param.{mod}.{k}", eng.W(mod, k).cpu().numpy(), p.detach().numpy(), 2e-5, 1e-5, rep)
+    finally:
+        print("\n".join(rep[-80:]))
+
+
 def test_wide_batch_uses_two_column_blocks_per_cluster_member():
     """B = 320 sequences = 20 row tiles: 20 x 13 single-block members would not be co-resident on 256 CUs, so the observe
     scans run with 7 members per tile owning two GRU column blocks each (observe_cluster.hip, pick_cluster).  One whole
