@@ -87,7 +87,7 @@ class ImagineFwdArgs(C.Structure):
         ["w_a4m", "w_a4s", "b_a4", "start_feat", "eps_action", "eps_entropy", "eps_prior"]) + [
         ("min_std", F32), ("act_raw_init_std", F32), ("act_min_std", F32), ("act_mean_scale", F32)] + _ptr_fields(
         ["feat", "prior_mean", "prior_std", "entropy", "action", "sv_actor", "sv_act_stats", "sv_x", "sv_gates",
-         "sv_p"]))
+         "sv_p"]) + [("sv_actor_stride", C.c_size_t)])
 
 
 class ImagineBwdArgs(C.Structure):

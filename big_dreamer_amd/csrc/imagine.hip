@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
     lds_barrier();
 
     const GruW gw{a.w_ir, a.w_iz, a.w_in, a.w_hr, a.w_hz, a.w_hn, a.b_ih, a.b_hh};
-    const size_t act_stride = (size_t)a.Hm * a.N * a.Hd;
+    const size_t act_stride = a.sv_actor_stride ? a.sv_actor_stride : (size_t)a.Hm * a.N * a.Hd;
     const float inv_ns = 1.f / (float)a.n_samples;
 
     for (int t = 0; t < a.Hm; ++t) {

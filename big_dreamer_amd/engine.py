@@ -171,6 +171,9 @@ class DreamerEngine:
         # by default (BD_OVERLAP_CRITIC=1 enables it; parity-tested either way).
         self.overlap_critic = os.environ.get("BD_OVERLAP_CRITIC", "0") == "1"
         self._side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("BD_SIDE_PRIO", "0")))
+        self._s_heads = torch.cuda.Stream(device=self.dev, priority=-1)     # heads of the first half of a split rollout
+        self.img_split = os.environ.get("BD_IMG_SPLIT", "0") == "1"
+        self._img_split_rows = 0
         # pixel mode: decoder weight gradients under the observe scan
         self._s_early = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("BD_EARLY_PRIO", "0")))
         # Cross-step software pipeline (on unless BD_PIPELINE=0).  Dynamics learning of step k+1 reads only the world
@@ -552,15 +555,22 @@ class DreamerEngine:
                                              ptr(pst), cabi.stream()))
         return pst, pm, ps
 
-    def dense_forward(self, mod: str, prefix: str, tag: str, x, ldx: int, M: int, out_width: int):
+    def dense_forward(self, mod: str, prefix: str, tag: str, x, ldx: int, M: int, out_width: int, rows=None):
+        """DenseModel forward with saved activations; `rows` = (r0, r1) runs that row range only (same buffers)."""
         d = self.d
         layers = self._dense_spec(mod, prefix, ldx, out_width)
         acts = [self.buf(f"{tag}_act{l}", M, d.Hd) for l in range(DENSE_LAYERS)]
         out = self.buf(f"{tag}_out", M, out_width)
-        self.mlp_forward(M, x, ldx, ldx, layers, acts + [None], out, out_width)
+        if rows is None:
+            self.mlp_forward(M, x, ldx, ldx, layers, acts + [None], out, out_width)
+        else:
+            r0, r1 = rows
+            self.mlp_forward(r1 - r0, x.view(M, ldx)[r0:r1], ldx, ldx, layers, [t[r0:r1] for t in acts] + [None],
+                             out[r0:r1], out_width)
         return out, acts, layers
 
-    def imagine(self, start_feat, N: int, Hm: int, noise, save: bool = True, tag: str = "", feat_tag: str = ""):
+    def imagine(self, start_feat, N: int, Hm: int, noise, save: bool = True, tag: str = "", feat_tag: str = "",
+                split: bool = False):
         d, pk = self.d, self.pk
         tm = lambda n: self.W("transition_model", n)
         ac = lambda n: self.W("actor", n)
@@ -594,8 +604,36 @@ class DreamerEngine:
             a.sv_act_stats = ptr(self.buf("sv_act_stats", Mi, 4 * d.A))
             a.sv_x, a.sv_gates = ptr(self.buf("isv_x", Mi, d.Be)), ptr(self.buf("isv_gates", Mi, 4 * d.Be))
             a.sv_p = ptr(self.buf("isv_p", Mi, d.Hd))
+        H1 = Hm // 2 if (split and Hm >= 2) else 0
         with self.span("imagine_fwd"):
-            cabi.check(lib.bd_imagine_forward(C.byref(a), cabi.stream()))
+            if not H1:
+                cabi.check(lib.bd_imagine_forward(C.byref(a), cabi.stream()))
+            else:
+                # two time segments: the frozen reward / value heads of the first can run under the second
+                # (_behaviour_phase).  Same kernel, same operands per step: bit-identical to one launch.
+                a.sv_actor_stride = Mi * d.Hd
+                a.Hm = H1
+                cabi.check(lib.bd_imagine_forward(C.byref(a), cabi.stream()))
+                self._ev_img_half = torch.cuda.Event()
+                self._ev_img_half.record(torch.cuda.current_stream())
+                r0 = H1 * N
+                f4 = 4      # bytes per float
+                a.Hm = Hm - H1
+                a.start_feat = ptr(ifeat) + (r0 - N) * (d.Be + d.S) * f4
+                a.eps_action = ptr(noise["action"]) + r0 * d.A * f4
+                a.eps_entropy = ptr(noise["entropy"]) + r0 * d.n_entropy * d.A * f4
+                a.eps_prior = ptr(noise["img_prior"]) + r0 * d.S * f4
+                a.feat = ptr(ifeat) + r0 * (d.Be + d.S) * f4
+                a.prior_mean = a.prior_mean + r0 * d.S * f4
+                a.prior_std = a.prior_std + r0 * d.S * f4
+                a.entropy, a.action = ptr(ent) + r0 * f4, ptr(act) + r0 * d.A * f4
+                if save:
+                    a.sv_actor = a.sv_actor + r0 * d.Hd * f4
+                    a.sv_act_stats = a.sv_act_stats + r0 * 4 * d.A * f4
+                    a.sv_x, a.sv_gates = a.sv_x + r0 * d.Be * f4, a.sv_gates + r0 * 4 * d.Be * f4
+                    a.sv_p = a.sv_p + r0 * d.Hd * f4
+                cabi.check(lib.bd_imagine_forward(C.byref(a), cabi.stream()))
+        self._img_split_rows = H1 * N
         return ifeat, ent, act
 
     # ------------------------------------------------------------------------------------------ train step
@@ -936,10 +974,20 @@ class DreamerEngine:
         ptag = "" if par is None else f"p{par}_"
         if par is not None and self._ev_cr_done[par] is not None:
             torch.cuda.current_stream().wait_event(self._ev_cr_done[par])     # critic of two steps ago: last reader
-        ifeat, ent, act = self.imagine(feat, N, Hm, noise, feat_tag=ptag)
+        ifeat, ent, act = self.imagine(feat, N, Hm, noise, feat_tag=ptag, split=self.img_split)
+        r0 = self._img_split_rows
         with self.span("img_heads_fwd"):
-            r_out, r_acts, r_layers = self.dense_forward("reward_model", "rew", "ir", ifeat, F, Mi, 1)
-            v_out, v_acts, v_layers = self.dense_forward("critic_target", "tgt", "iv", ifeat, F, Mi, 1)
+            if not r0:
+                r_out, r_acts, r_layers = self.dense_forward("reward_model", "rew", "ir", ifeat, F, Mi, 1)
+                v_out, v_acts, v_layers = self.dense_forward("critic_target", "tgt", "iv", ifeat, F, Mi, 1)
+            else:       # rows of the first time segment on a helper stream, under the second segment of the rollout
+                with torch.cuda.stream(self._s_heads):
+                    self._s_heads.wait_event(self._ev_img_half)
+                    self.dense_forward("reward_model", "rew", "ir", ifeat, F, Mi, 1, rows=(0, r0))
+                    self.dense_forward("critic_target", "tgt", "iv", ifeat, F, Mi, 1, rows=(0, r0))
+                r_out, r_acts, r_layers = self.dense_forward("reward_model", "rew", "ir", ifeat, F, Mi, 1, rows=(r0, Mi))
+                v_out, v_acts, v_layers = self.dense_forward("critic_target", "tgt", "iv", ifeat, F, Mi, 1, rows=(r0, Mi))
+                torch.cuda.current_stream().wait_stream(self._s_heads)
         returns = self.buf(ptag + "returns", Mi)
         cabi.check(lib.bd_lambda_return_forward(ptr(r_out), ptr(v_out), Hm, N, hp["discount"], hp["disclam"], ptr(returns), st))
         cabi.check(lib.bd_sum(ptr(returns), Mi, sc, SLOT_RET, ws, st))

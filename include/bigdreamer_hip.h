@@ -275,6 +275,8 @@ typedef struct {
     float* sv_x;          /* [Hm x N x Be]                                                          */
     float* sv_gates;      /* [Hm x N x 4*Be]                                                        */
     float* sv_p;          /* [Hm x N x Hd]                                                          */
+    size_t sv_actor_stride; /* floats between the layers of sv_actor; 0 = Hm*N*Hd.  Lets a rollout be launched in
+                               two time segments (second segment: Hm, start_feat and every [Hm x ...] pointer shifted) */
 } bd_imagine_fwd_args;
 int bd_imagine_forward(const bd_imagine_fwd_args* a, void* stream);
 

@@ -239,10 +239,12 @@ def test_pipelined_schedule_is_bit_identical_to_serial(name):
     d, seed, hp, _full = CASES[name]
     P = synth.make_params(d, seed)
     engs = []
-    for pipe, defer in ((True, False), (False, False), (True, True)):
+    for pipe, defer, split in ((True, False, False), (False, False, False), (True, True, False), (True, False, True),
+                               (False, False, True)):
         eng = DreamerEngine(d, hp, "cuda", params=P)
         eng.pipeline = pipe
         eng.defer_opt = defer        # the data-parallel order of the optimiser steps (engine._optimizer_step_or_defer)
+        eng.img_split = split        # imagination launched in two time segments, heads of the first under the second
         engs.append(eng)
     steps = 4
     batches = [_dev(synth.make_batch(d, seed + 10 * i)) for i in range(steps)]
