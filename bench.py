@@ -2,7 +2,8 @@
 """bench.py -- latent transitions/sec of the Dreamer world-model training step on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-(N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+(N>1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py
+--gpus N ...`, or plain `python bench.py --gpus N`, which then spawns its own N rank processes -- big_dreamer_amd/launch.py)
 
 One step = one full Dreamer.train_step (RSSM observe scan + imagination, forward + backward + three
 clip/Adam updates; reference src/dreamer.py:253-393) on one replay batch of BASELINE.json configs[1]:
@@ -48,11 +49,13 @@ def algorithmic(d):
     return flops, step_bytes
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_traffic.json:
-    separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled for gfx950).  None if absent."""
+def measured_traffic(kernel, kind=""):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary of the SAME workload
+    (profiles/*_traffic.json for configs[1], profiles/*_pixel_traffic.json for configs[2]: separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes, FETCH_SIZE doubled for gfx950).  None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))
+                   if ("_pixel_" in os.path.basename(f)) == (kind == "pixel"))
     if not files:
         return None, None
     t = json.load(open(files[-1])).get(kernel)
@@ -100,45 +103,26 @@ def cpu_baseline(d, budget_s=15.0, max_steps=8):   # (pixel: ~8 s per step -> 1-
                       f"{dt / steps * 1e3:.0f} ms/step"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pixel", action="store_true",
-                    help="BASELINE.json configs[2] (64x64 pixel observations, action dim 17) instead of the default configs[1]")
-    args = ap.parse_args()
+def decoder_wgrad_flops(d):
+    """Algorithmic FLOPs of ONE launch of the decoder's grouped weight-gradient GEMM (the dominant kernel of the pixel
+    step): dW of ConvT(32,3,k6) / ConvT(64,32,k6) / ConvT(128,64,k5) as gathered-window GEMMs, the 1x1 -> 5x5 layer and
+    Linear(Be+S, E) as plain GEMMs (conv_stack.backward_decoder), 2*M*N*K each, per image x N images."""
+    F = d.Be + d.S
+    per_img = 2 * (900 * 32 * 108 + 169 * 64 * 1152 + 25 * 128 * 1600 + d.E * 3200 + d.E * F)
+    return per_img * d.N
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist_on = world > 1 or os.environ.get("BD_FORCE_DP", "0") == "1"    # BD_FORCE_DP=1: one-rank rehearsal of the RCCL path
-    if dist_on:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
+def run_workload(d, pixel, args, rank, world, dev, dist_on, steps, warmup, timers=True):
+    """Build engine + HBM-resident synthetic replay for `d`, run warmup + exactly `steps` timed train steps between
+    barrier + synchronise fences.  Returns (dt max over ranks, HIP-event spans, last logs, engine)."""
+    import torch.distributed as dist
     from big_dreamer_amd import synth
     from big_dreamer_amd.engine import DreamerEngine
     from big_dreamer_amd.memory import ExperienceReplay
-
-    # Drive the engine from a non-blocking stream rather than the legacy null stream, which synchronises implicitly with
-    # every blocking stream of the process; the fences below are device-wide synchronisations.
-    torch.cuda.set_stream(torch.cuda.Stream(dev))
-    d = synth.CONFIG3 if args.pixel else synth.CONFIG2
-    np.random.seed(rank)
-    torch.manual_seed(rank)
-    # (one communicator: the engine issues the actor / critic all-reduces one host step late so that they never sit in
-    # front of the next step's world-model all-reduce -- engine._optimizer_step_or_defer)
     eng = DreamerEngine(d, None, dev, params=synth.make_params(d, 0), world_size=world)
-    rep = synth.make_replay(d if not args.pixel else synth.Dims(A=d.A, O=3), rows=5000, seed=0)
-    buf = ExperienceReplay(5000, d.A, 5, args.pixel, d.O, dev)
-    if args.pixel:      # uniform uint8 frames
+    rep = synth.make_replay(d if not pixel else synth.Dims(A=d.A, O=3), rows=5000, seed=0)
+    buf = ExperienceReplay(5000, d.A, 5, pixel, d.O, dev)
+    if pixel:      # uniform uint8 frames (SURVEY.md section 8d)
         rep["observations"] = np.random.default_rng(0).integers(0, 256, size=(5000, 3, 64, 64), dtype=np.uint8)
     for k, v in rep.items():
         getattr(buf, k)[:] = v
@@ -149,47 +133,137 @@ def main():
         o, a, r, n = buf.sample(d.B, d.L)
         eng.train_step({"observations": o, "actions": a, "rewards": r, "nonterminals": n}, None, sync_logs=False)
 
-    log(f"rank {rank}/{world}: engine built, replay resident; warm-up {args.warmup} steps")
-    for _ in range(args.warmup):
+    log(f"rank {rank}/{world}: engine built ({'pixel' if pixel else 'state'} obs, A={d.A}), replay resident; warm-up {warmup} steps")
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    log("warm-up done; timing")
-    # HIP-event spans on every 5th step of the timed region (each span costs two queue packets); the host's cyclic
-    # garbage collector is parked for the timed loop (a generation-2 pass over the imported modules stalls the
-    # enqueueing thread for ~40 ms, i.e. ten steps of GPU work)
-    import gc
-    gc.collect()
-    gc.freeze()
-    eng.enable_timers(True, every=5 if args.steps >= 10 else 1)
+    # HIP-event spans on every 5th step of the timed region (each span costs two queue packets)
+    if timers:
+        eng.enable_timers(True, every=5 if steps >= 10 else 1)
 
     def fence():
-        eng.join()          # everything queued on the engine's streams, incl. optimiser steps it issues one step late
+        eng.flush_optimizers()   # optimiser steps the data-parallel schedule issues one host step late (collectives)
+        eng.join()               # everything queued on the engine's streams
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    log(f"timed {args.steps} steps in {dt * 1e3:.1f} ms")
+    log(f"timed {steps} steps in {dt * 1e3:.1f} ms")
     logs = eng.logs()
     if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    kt = eng.timer_summary()          # {kernel: (avg ms, launches)} from HIP events on the launch stream
+    kt = eng.timer_summary() if timers else {}
     eng.enable_timers(False)
+    return dt, kt, logs, eng
 
+
+def surface_ms_per_step(d, dev, steps, warmup, burst=5):
+    """The same workload through the reference's call surface: ``Dreamer(params, env).train_step()`` in bursts of
+    `burst` = collect_interval steps, reading the LAST log dict of each burst as src/main.py:103-108 does."""
+    from big_dreamer_amd import synth
+    from big_dreamer_amd.config import load_config
+    from big_dreamer_amd.dreamer import Dreamer
+
+    class _Env:
+        action_size, observation_size = d.A, d.O
+
+    params = load_config([f"batch_size={d.B}", f"seq_len={d.L}", f"planning_horizon={d.H}", f"belief_size={d.Be}",
+                          f"state_size={d.S}", f"hidden_size={d.Hd}", f"embedding_size={d.E}", "experience_size=5000",
+                          "pixel_observation=false"])
+    torch.manual_seed(0)
+    agent = Dreamer(params, _Env(), device=str(dev))
+    rep = synth.make_replay(d, rows=5000, seed=0)
+    for k, v in rep.items():
+        getattr(agent.buffer, k)[:] = v
+    agent.buffer.idx, agent.buffer.full = 0, True
+    agent.buffer.sync_device()
+    logs = None
+    for _ in range(warmup):
+        logs = agent.train_step()
+    float(logs["model_loss"])
+    torch.cuda.synchronize()
+    bursts = max(1, steps // burst)
+    t0 = time.perf_counter()
+    for _ in range(bursts):
+        for _ in range(burst):
+            logs = agent.train_step()
+        float(logs["model_loss"])            # the loop reads the burst's last dict (weight_update_per_sec, logging)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dt / (bursts * burst) * 1e3, {k: round(float(v), 5) for k, v in logs.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the surface and pixel-config legs (profiling runs)")
+    ap.add_argument("--pixel", action="store_true",
+                    help="BASELINE.json configs[2] (64x64 pixel observations, action dim 17) instead of the default configs[1]")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo: tests only)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="tests only: every rank on cuda:0 (needs --backend gloo: RCCL refuses two ranks on one device)")
+    args = ap.parse_args()
+
+    from big_dreamer_amd import launch
+    if args.gpus > 1 and not launch.launched_by_torchrun():
+        # plain `python bench.py --gpus N`: become the launcher -- N fresh rank processes of this script, one per GPU;
+        # this parent never touches HIP.  Rank 0 prints the JSON line.
+        sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist_on = world > 1 or os.environ.get("BD_FORCE_DP", "0") == "1"    # BD_FORCE_DP=1: one-rank rehearsal of the RCCL path
+    rccl_ranks = 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        rccl_ranks = dist.get_world_size()
+
+    from big_dreamer_amd import synth
+
+    # Drive the engine from a non-blocking stream rather than the legacy null stream, which synchronises implicitly with
+    # every blocking stream of the process (DESIGN.md section 6); the fences are device-wide synchronisations.
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
+    d = synth.CONFIG3 if args.pixel else synth.CONFIG2
+    np.random.seed(rank)
+    torch.manual_seed(rank)
+    # the host's cyclic garbage collector is parked for the timed loops (a generation-2 pass over the imported modules
+    # stalls the enqueueing thread for ~40 ms, i.e. ten steps of GPU work)
+    import gc
+    gc.collect()
+    gc.freeze()
+    # (one communicator: the engine issues the actor / critic all-reduces one host step late so that they never sit in
+    # front of the next step's world-model all-reduce -- engine._optimizer_step_or_defer)
+    dt, kt, logs, eng = run_workload(d, args.pixel, args, rank, world, dev, dist_on, args.steps, args.warmup)
+
+    out = None
     if rank == 0:
         flops, step_bytes = algorithmic(d)
         # dominant kernel = the persistent kernel that carries most of the path's algorithmic FLOPs (the imagination
         # forward: 31.9 of the 63.6 GFLOP of the four scans); every kernel's rate is listed in kernel_tflops
         dom = max((k for k in kt if k in flops), key=lambda k: flops[k])
         ach = flops[dom] / (kt[dom][0] * 1e-3) / 1e12
-        traffic, traffic_src = measured_traffic(dom)
+        traffic, traffic_src = measured_traffic(dom, "pixel" if args.pixel else "")
         out = {
             "metric": "latent transitions/sec (RSSM + imagination) at batch=50 chunk=50 H=15",
             "value": d.transitions_per_step * args.steps * world / dt,
@@ -198,6 +272,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "rccl_ranks": rccl_ranks, "backend": (args.backend if dist_on else None),
             "schedule": ("cross-step pipeline on 3 HIP streams (dynamics learning k+1 | behaviour learning k | critic k)"
                          if eng.pipeline else "serial, one stream"),
             "config": {"workload": ("BASELINE.json configs[2]: 64x64 pixel-obs Dreamer train_step (conv stacks on "
@@ -219,10 +294,47 @@ def main():
             "kernel_ms": {k: round(v[0], 4) for k, v in kt.items()},
             "losses": {k: round(v, 5) for k, v in logs.items()},
         }
+    del eng
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_secondary and not args.pixel:
+        # (a) the same workload through the reference's call surface (Dreamer.train_step, lazy log dicts)
+        sms, slogs = surface_ms_per_step(d, dev, args.steps, args.warmup)
+        out["surface_ms_per_step"] = sms
+        out["surface"] = {"ms_per_step": sms, "value": d.transitions_per_step / (sms * 1e-3),
+                          "how": "Dreamer(params, env).train_step() in bursts of collect_interval=5, last log dict of each "
+                                 "burst read (src/main.py:103-108); `value`/`ms_per_step` above drive the engine directly",
+                          "losses": slogs}
+        torch.cuda.empty_cache()
+        # (b) BASELINE.json configs[2] (pixels, A=17) in the same process: its step time and the roofline of ITS
+        #     dominant kernel, the decoder's grouped weight-gradient GEMM (bench.py --pixel makes it the main line)
+        d3 = synth.CONFIG3
+        psteps = max(5, min(20, args.steps))
+        pdt, pkt, plogs, peng = run_workload(d3, True, args, rank, world, dev, False, psteps, 3)
+        pdom = "wgrad_gemm_model_early"
+        pfl = decoder_wgrad_flops(d3)
+        pach = pfl / (pkt[pdom][0] * 1e-3) / 1e12
+        ptraffic, psrc = measured_traffic("wgrad_decoder", "pixel")
+        out["secondary"] = {
+            "workload": "BASELINE.json configs[2]: 64x64 pixel-obs Dreamer train_step, conv encoder/decoder on this "
+                        "library's gather-GEMM kernels, action=17, batch=50 chunk=50 H=15",
+            "value": d3.transitions_per_step * psteps / pdt, "unit": "latent transitions/s",
+            "ms_per_step": pdt / psteps * 1e3, "steps": psteps, "warmup": 3,
+            "roofline": {"bound": "mfma", "kernel": "wgrad_wide_kernel (decoder conv weight gradients, one grouped launch)",
+                         "achieved": pach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": pach / FP32_MFMA_PEAK_TFLOPS, "traffic": ptraffic, "traffic_source": psrc,
+                         "avg_launch_ms": pkt[pdom][0], "launches_timed": pkt[pdom][1],
+                         "algorithmic_flop_per_launch": pfl},
+            "kernel_ms": {k: round(v[0], 4) for k, v in pkt.items()},
+            "losses": {k: round(v, 5) for k, v in plogs.items()},
+        }
+        del peng
+        torch.cuda.empty_cache()
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist_on:
+        dist.barrier()
         dist.destroy_process_group()
 
 

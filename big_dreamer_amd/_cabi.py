@@ -127,6 +127,7 @@ _SIGS = {
     "bd_wgrad": (I32, [P, I32, P, I32, I32, I32, I32, P, I32, P, I32, P, C.c_size_t, P]),
     "bd_wgrad_plan": (I32, [C.POINTER(WgradDesc), I32, C.POINTER(I32), C.POINTER(I32), C.POINTER(C.c_size_t)]),
     "bd_wgrad_grouped": (I32, [P, I32, I32, I32, P, P]),
+    "bd_wgrad_grouped_phase": (I32, [P, I32, I32, I32, P, I32, P]),
     "bd_observe_forward": (I32, [C.POINTER(ObserveFwdArgs), P]),
     "bd_observe_backward": (I32, [C.POINTER(ObserveBwdArgs), P]),
     "bd_observe_cluster_size": (I32, [I32, I32]),
@@ -134,6 +135,8 @@ _SIGS = {
     "bd_observe_forward_cluster": (I32, [C.POINTER(ObserveFwdArgs), P, C.c_size_t, P]),
     "bd_observe_backward_cluster": (I32, [C.POINTER(ObserveBwdArgs), P, C.c_size_t, P]),
     "bd_observe_cluster_status": (I32, [P, I32, P]),
+    "bd_observe_cluster_err_offset": (C.c_size_t, [I32]),
+    "bd_observe_cluster_set_spin_limit": (I32, [C.c_uint]),
     "bd_gauss_head_forward": (I32, [P, P, I32, I32, F32, P, P, P, P]),
     "bd_gauss_head_backward": (I32, [P, P, P, P, P, I32, I32, P, P]),
     "bd_imagine_forward": (I32, [C.POINTER(ImagineFwdArgs), P]),
@@ -182,10 +185,16 @@ def check(rc: int) -> None:
 
 
 def ptr(t) -> int:
-    """Device pointer of a tensor (None -> NULL)."""
+    """Device pointer of a tensor (None -> NULL).  The kernels read every operand as dense row-major with the leading
+    dimension the caller states, so a tensor must be contiguous or a row-strided 2-D view of one (unit inner stride,
+    e.g. ``W[:, :S]`` or ``feat[:, :Be]``): a permuted or column-strided view would be read with the wrong strides."""
     if t is None:
         return None
-    assert t.dtype in (torch.float32, torch.int64, torch.uint8) and t.is_cuda, "expected a CUDA fp32/int64/uint8 tensor"
+    if not (t.dtype in (torch.float32, torch.int64, torch.uint8) and t.is_cuda):
+        raise TypeError("expected a CUDA fp32/int64/uint8 tensor")
+    if not (t.is_contiguous() or (t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1])):
+        raise ValueError(f"non-contiguous tensor (shape {tuple(t.shape)}, strides {t.stride()}) passed to a HIP kernel: "
+                         "call .contiguous() first")
     return t.data_ptr()
 
 

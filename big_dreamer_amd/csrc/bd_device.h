@@ -288,7 +288,8 @@ __device__ __forceinline__ void linear_blocks(const Seg (&seg)[NSEG], const floa
 static __device__ unsigned long long g_dstamps[64];
 #define BD_DSTAMP(base, k)                                                                                  \
     do {                                                                                                    \
-        if ((base) >= 0 && blockIdx.x == 0 && threadIdx.x == 0) g_dstamps[(base) + (k)] = __builtin_amdgcn_s_memtime(); \
+        if ((base) >= 0 && (base) + (k) < 64 && blockIdx.x == 0 && threadIdx.x == 0)                        \
+            g_dstamps[(base) + (k)] = __builtin_amdgcn_s_memtime();                                          \
     } while (0)
 #else
 #define BD_DSTAMP(base, k)

@@ -16,8 +16,9 @@
 //             reached the epoch -> workgroup barrier -> EVERY load of the payload is an sc1 load to registers.
 //   Epoch = step + 1 (monotonic within a launch, never 0); flags are zeroed by a memset node ahead of the launch;
 //   the payload is double-buffered by step parity (a member can run at most one step ahead of the slowest).
-//   Every spin is bounded: on timeout the member sets the error word and stops waiting (outputs are then wrong, the
-//   launch still terminates; bd_observe_cluster_status reports it).
+//   Every spin is bounded: on timeout the member ORs its code into the STICKY error word and stops waiting (outputs are
+//   then wrong, the launch still terminates).  The error word is NOT part of the per-launch header memset: it survives
+//   later launches until bd_observe_cluster_status reads (and clears) it -- the engine reads it with every log fetch.
 // Residency: tiles*C <= 256 workgroups of one per CU are co-resident on an otherwise idle MI355X.
 #include "bd_device.h"
 #include "bd_host.h"
@@ -38,6 +39,8 @@ __device__ unsigned long long g_cstamps[64];
 #endif
 constexpr int kLocalBlocks = 2;             // column blocks a member owns at most (host picks C accordingly)
 constexpr unsigned kSpinLimit = 1u << 22;   // ~ seconds; far beyond any legitimate wait
+static unsigned g_spin_limit = kSpinLimit;  // host copy, passed to every launch (bd_observe_cluster_set_spin_limit: tests)
+constexpr unsigned kErrFwd = 1u, kErrBwd = 2u;
 
 struct ObsDimsC {
     int Kb_h, Kb_s, Kb_a, Kb_hd;
@@ -45,8 +48,9 @@ struct ObsDimsC {
         : Kb_h(cdiv(Be, 16)), Kb_s(cdiv(S, 16)), Kb_a(cdiv(A, 16)), Kb_hd(cdiv(Hd, 16)) {}
 };
 
-// workspace: [flags: tiles*kMaxCluster u32][err: 16 u32][payload: tiles * 2 parities * nvec * Kb_h*256 floats]
-__host__ __device__ inline size_t cluster_ws_header_floats(int tiles) { return (size_t)tiles * kMaxCluster + 16; }
+// workspace: [flags: tiles*kMaxCluster u32][err: 16 u32, sticky][payload: tiles * 2 parities * nvec * Kb_h*256 floats]
+__host__ __device__ inline size_t cluster_ws_flag_floats(int tiles) { return (size_t)tiles * kMaxCluster; }
+__host__ __device__ inline size_t cluster_ws_header_floats(int tiles) { return cluster_ws_flag_floats(tiles) + 16; }
 
 __device__ __forceinline__ void st_sc1(float* p, float v) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -63,7 +67,8 @@ __device__ __forceinline__ void publish(unsigned* flag, unsigned epoch) {
 }
 
 // wave 0 polls the C member flags of this tile; returns after a workgroup barrier
-__device__ __forceinline__ void wait_all(const unsigned* flags, int C, unsigned epoch, unsigned* err) {
+__device__ __forceinline__ void wait_all(const unsigned* flags, int C, unsigned epoch, unsigned* err, unsigned limit,
+                                         unsigned code) {
     if ((threadIdx.x >> 6) == 0) {
         const int lane = threadIdx.x & 63;
         unsigned spins = 0;
@@ -71,8 +76,8 @@ __device__ __forceinline__ void wait_all(const unsigned* flags, int C, unsigned 
             unsigned v = epoch;
             if (lane < C) v = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all(v >= epoch)) break;
-            if (++spins > kSpinLimit) {
-                if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > limit) {
+                if (lane == 0) __hip_atomic_fetch_or(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
@@ -92,7 +97,7 @@ __device__ __forceinline__ void gather_payload(const float* __restrict__ src, fl
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_args a, float* __restrict__ ws, int C,
-                                                                int tiles) {
+                                                                int tiles, unsigned spin_limit) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ObsDimsC d(a.Be, a.S, a.A, a.Hd);
     const int tile = blockIdx.x / C, c = blockIdx.x - tile * C;
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
             }
         }
         BD_CSTAMP(6);
-        wait_all(flags, C, (unsigned)(t + 1), err);
+        wait_all(flags, C, (unsigned)(t + 1), err, spin_limit, kErrFwd);
         BD_CSTAMP(7);
         gather_payload(xbuf + (size_t)(t & 1) * nh, h_nxt, nh);
         lds_barrier();
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
 
 // ---- backward --------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_args a, float* __restrict__ ws, int C,
-                                                                int tiles) {
+                                                                int tiles, unsigned spin_limit) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ObsDimsC d(a.Be, a.S, a.A, a.Hd);
     const int tile = blockIdx.x / C, c = blockIdx.x - tile * C;
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
                 if (grow < a.B && col < a.Be) a.d_embed_pre[(tb + grow) * a.Be + col] = de_keep[r];
             }
         }
-        wait_all(flags, C, epoch, err);
+        wait_all(flags, C, epoch, err, spin_limit, kErrBwd);
         gather_payload(xbuf + (size_t)(epoch & 1) * (2 * nh), dhc, 2 * nh);
         lds_barrier();
         // ---- 5: d posterior_state_t through the embed layer and the nonterminal mask (every member) ----
@@ -573,9 +578,25 @@ static int pick_cluster(int B, int Be) {
 // slots with another stream's workgroups slows the whole cluster (measured under the engine's cross-step pipeline:
 // observe_bwd 1.0 -> 1.75 ms).  Requesting the CU's whole LDS keeps every LDS-using kernel of the other streams off
 // a member's CU.  BD_OBS_EXCLUSIVE=0 launches with the LDS the kernel needs.
-static size_t launch_lds(size_t need) {
+// A workgroup's LDS allocation is static + dynamic: the dynamic request is what is left of the CU's LDS after the
+// kernel's static __shared__ (0 in the product build; a diagnostic build that adds any would otherwise ask for more than
+// the CU has and the queue aborts with HSA_STATUS_ERROR_INVALID_ALLOCATION instead of returning an error).
+// Returns 0 and sets the error text when `need` does not fit.
+template <class K>
+static size_t launch_lds(K kernel, size_t need, const char* who) {
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(kernel)) != hipSuccess) {
+        fail("%s: hipFuncGetAttributes failed", who);
+        return 0;
+    }
+    const size_t room = (size_t)kMaxLds > at.sharedSizeBytes ? (size_t)kMaxLds - at.sharedSizeBytes : 0;
+    if (need > room) {
+        fail("%s: needs %zu B of dynamic LDS, %zu B available beside %zu B of static __shared__", who, need, room,
+             (size_t)at.sharedSizeBytes);
+        return 0;
+    }
     static const char* e = getenv("BD_OBS_EXCLUSIVE");
-    return (e && e[0] == '0') ? need : (size_t)kMaxLds;
+    return (e && e[0] == '0') ? need : room;
 }
 
 static size_t scratch_floats_fwd() {
@@ -605,15 +626,25 @@ size_t bd_observe_cluster_ws_floats(int B, int Be) {
     return cluster_ws_header_floats(tiles) + (size_t)tiles * 2 * 2 * cdiv(Be, 16) * kFragFloats;
 }
 
-// 0 = no member timed out in the last cluster launch that used `ws` (reads the error word: synchronises)
-int bd_observe_cluster_status(const float* ws, int B, void* stream) {
-    const int tiles = cdiv(B, 16);
+size_t bd_observe_cluster_err_offset(int B) { return cluster_ws_flag_floats(cdiv(B, 16)); }
+
+int bd_observe_cluster_set_spin_limit(unsigned limit) {
+    g_spin_limit = limit ? limit : kSpinLimit;
+    return 0;
+}
+
+// 0 = no member has timed out in ANY cluster launch that used `ws` since the last call (the error word is sticky:
+// launches never clear it).  Reads and clears the word: synchronises `stream`.
+int bd_observe_cluster_status(float* ws, int B, void* stream) {
+    unsigned* w = reinterpret_cast<unsigned*>(ws) + bd_observe_cluster_err_offset(B);
     unsigned e = 0;
-    if (hipMemcpyAsync(&e, reinterpret_cast<const unsigned*>(ws) + tiles * kMaxCluster, sizeof(e), hipMemcpyDeviceToHost,
-                       (hipStream_t)stream) != hipSuccess ||
+    if (hipMemcpyAsync(&e, w, sizeof(e), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
         hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
         return fail("bd_observe_cluster_status: copy failed");
-    return e == 0 ? 0 : fail("bd_observe_cluster_status: a cluster member timed out waiting for its peers");
+    if (e == 0) return 0;
+    if (hipMemsetAsync(w, 0, sizeof(e), (hipStream_t)stream) != hipSuccess) return fail("bd_observe_cluster_status: clear failed");
+    return fail("bd_observe_cluster_status: a cluster member timed out waiting for its peers (%s%s scan): results of that "
+                "launch are wrong", (e & kErrFwd) ? "forward" : "", (e & kErrBwd) ? ((e & kErrFwd) ? "+backward" : "backward") : "");
 }
 
 int bd_observe_forward_cluster(const bd_observe_fwd_args* a, float* ws, size_t ws_floats, void* stream) {
@@ -633,10 +664,12 @@ int bd_observe_forward_cluster(const bd_observe_fwd_args* a, float* ws, size_t w
                        sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_observe_forward_cluster: needs %zu B of LDS", lds);
     if (allow_big_lds(observe_cfwd_kernel)) return -1;
-    if (hipMemsetAsync(ws, 0, cluster_ws_header_floats(tiles) * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    const size_t dyn = launch_lds(observe_cfwd_kernel, lds, "bd_observe_forward_cluster");
+    if (!dyn) return -1;
+    if (hipMemsetAsync(ws, 0, cluster_ws_flag_floats(tiles) * sizeof(float), (hipStream_t)stream) != hipSuccess)
         return fail("bd_observe_forward_cluster: memset failed");
-    hipLaunchKernelGGL(observe_cfwd_kernel, dim3(tiles * C), dim3(kThreads), launch_lds(lds), (hipStream_t)stream, *a, ws, C,
-                       tiles);
+    hipLaunchKernelGGL(observe_cfwd_kernel, dim3(tiles * C), dim3(kThreads), dyn, (hipStream_t)stream, *a, ws, C, tiles,
+                       g_spin_limit);
     BD_CHECK_LAUNCH("bd_observe_forward_cluster");
     return 0;
 }
@@ -657,10 +690,12 @@ int bd_observe_backward_cluster(const bd_observe_bwd_args* a, float* ws, size_t 
                        sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_observe_backward_cluster: needs %zu B of LDS", lds);
     if (allow_big_lds(observe_cbwd_kernel)) return -1;
-    if (hipMemsetAsync(ws, 0, cluster_ws_header_floats(tiles) * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    const size_t dyn = launch_lds(observe_cbwd_kernel, lds, "bd_observe_backward_cluster");
+    if (!dyn) return -1;
+    if (hipMemsetAsync(ws, 0, cluster_ws_flag_floats(tiles) * sizeof(float), (hipStream_t)stream) != hipSuccess)
         return fail("bd_observe_backward_cluster: memset failed");
-    hipLaunchKernelGGL(observe_cbwd_kernel, dim3(tiles * C), dim3(kThreads), launch_lds(lds), (hipStream_t)stream, *a, ws, C,
-                       tiles);
+    hipLaunchKernelGGL(observe_cbwd_kernel, dim3(tiles * C), dim3(kThreads), dyn, (hipStream_t)stream, *a, ws, C, tiles,
+                       g_spin_limit);
     BD_CHECK_LAUNCH("bd_observe_backward_cluster");
     return 0;
 }

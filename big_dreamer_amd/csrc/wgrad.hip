@@ -509,10 +509,16 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
 
 int bd_wgrad_grouped(const bd_wgrad_desc* descs_dev, int n, int total_blocks, int total_red_blocks, float* ws,
                      void* stream) {
+    return bd_wgrad_grouped_phase(descs_dev, n, total_blocks, total_red_blocks, ws, 0, stream);
+}
+
+int bd_wgrad_grouped_phase(const bd_wgrad_desc* descs_dev, int n, int total_blocks, int total_red_blocks, float* ws,
+                           int phase, void* stream) {
     using namespace bd;
-    BD_REQUIRE(descs_dev && ws && n > 0 && n <= 4096 && total_blocks > 0 && total_red_blocks > 0,
+    BD_REQUIRE(descs_dev && ws && n > 0 && n <= 4096 && total_blocks > 0 && total_red_blocks > 0 && phase >= 0 && phase <= 2,
                "bd_wgrad_grouped: bad arguments");
-    if (wgrad_wide()) {
+    if (phase == 2) {
+    } else if (wgrad_wide()) {
         static_assert(kThreads == 256, "the 64x64-tile wgrad kernels are written for four waves");
         static bool lds_ok = false;
         if (!lds_ok) {
@@ -525,6 +531,7 @@ int bd_wgrad_grouped(const bd_wgrad_desc* descs_dev, int n, int total_blocks, in
         hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(total_blocks), dim3(kThreads), 0, (hipStream_t)stream, descs_dev, n, ws);
     }
     BD_CHECK_LAUNCH("bd_wgrad_grouped");
+    if (phase == 1) return 0;
     hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3(total_red_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n,
                        ws);
     BD_CHECK_LAUNCH("bd_wgrad_grouped(reduce)");

@@ -102,12 +102,37 @@ class Dreamer:
 
     # ---------------------------------------------------------------------------------------- checkpoints
     def load(self, params: Dict[str, Any]) -> None:
-        """src/planet.py:103-114: load the reference's checkpoint dict (weights only, no code execution)."""
+        """src/planet.py:103-114: load the reference's checkpoint dict -- the four world-model state dicts AND
+        ``model_optimizer`` (Adam moments and step count, so a resumed run continues the reference's bias correction) --
+        with a loader that executes nothing from the file.  Checkpoints written by ``save`` below also restore the
+        actor, the critic and its target and their optimisers (the reference never saves those)."""
         path = params.get("models", "")
         if path and os.path.exists(path):
             d = torch.load(path, map_location="cpu", weights_only=True)
             for key in ("transition_model", "observation_model", "reward_model", "encoder"):
                 getattr(self, key).load_state_dict(d[key])
+            if "model_optimizer" in d:
+                self.engine.load_optimizer_state_dict("model", d["model_optimizer"])
+            for key in ("actor", "critic", "critic_target"):
+                if key in d:
+                    getattr(self, key).load_state_dict(d[key])
+            for key, group in (("actor_optimizer", "actor"), ("value_optimizer", "critic")):
+                if key in d:
+                    self.engine.load_optimizer_state_dict(group, d[key])
+
+    def save(self, path: str) -> None:
+        """Checkpoint in the layout ``Planet.load`` reads (src/planet.py:109-114: transition_model, observation_model,
+        reward_model, encoder, model_optimizer -- the reference can resume from it), plus actor / critic /
+        critic_target and their optimisers (src/dreamer.py:56-67 names) so that this framework resumes exactly.
+        The reference declares ``save`` (src/base_agent.py:29-34) but never implements it (src/main.py:274 TODO)."""
+        e = self.engine
+        d = {key: {k: v.detach().cpu().clone().contiguous() for k, v in getattr(self, key).state_dict().items()}
+             for key in ("transition_model", "observation_model", "reward_model", "encoder", "actor", "critic",
+                         "critic_target")}
+        d["model_optimizer"] = e.optimizer_state_dict("model")
+        d["actor_optimizer"] = e.optimizer_state_dict("actor")
+        d["value_optimizer"] = e.optimizer_state_dict("critic")
+        torch.save(d, path)
 
     def eval(self) -> None:      # no dropout / batch-norm anywhere on the path
         pass
@@ -137,9 +162,16 @@ class Dreamer:
     def train_step(self) -> Dict[str, float]:
         """src/dreamer.py:253-393.  Returns the reference's log dict."""
         obs, actions, rewards, nonterminals = self.buffer.sample(self.batch_size, self.seq_len)
-        logs = self.engine.train_step({"observations": obs, "actions": actions, "rewards": rewards,
-                                       "nonterminals": nonterminals})
-        return {k: v for k, v in logs.items() if not k.startswith("grad_norm")}
+        batch = {"observations": obs, "actions": actions, "rewards": rewards, "nonterminals": nonterminals}
+        if os.environ.get("BD_LAZY_LOGS", "1") == "0":       # eager: every call waits for the GPU, like the reference's .item()
+            logs = self.engine.train_step(batch)
+            return {k: v for k, v in logs.items() if not k.startswith("grad_norm")}
+        # Lazy mapping with the reference's keys: values are fetched when a key is first read, so the collect loop's burst
+        # `for _ in range(collect_interval): logs = model.train_step()` (src/main.py:105-108) keeps the cross-step
+        # pipeline full and only the dict it actually reads waits for the device.
+        logs = self.engine.train_step(batch, sync_logs="lazy")
+        logs._drop = ("grad_norm",)
+        return logs
 
     def update_critic(self) -> None:
         self.engine.update_critic()
@@ -195,15 +227,25 @@ class Dreamer:
         return act.view(N, d.A).clone(), ent.view(N).clone()
 
     @torch.no_grad()
-    def update_belief_and_act(self, env, belief, posterior_state, action, observation, explore=False):
-        """src/planet.py:370-403."""
+    def update_belief_and_act(self, env, belief, posterior_state, action, observation, explore=False,
+                              _noise: Optional[Dict[str, Tensor]] = None):
+        """src/planet.py:370-403.  (Data-parallel runs: issues any held-back actor update first -- a collective, call on
+        every rank, as the collect loop does.)"""
+        self.engine.flush_optimizers()
+        # `_noise` (parity tests): the reference's draws in its RNG order -- "prior" (B,S), "post" (B,S), "action" (B,A),
+        # "entropy" (100,B,A), and with explore "explore" (B,A)
+        nz = _noise
         embedding = self.encoder(observation.to(self.device)).unsqueeze(dim=0)
-        belief, _, _, posterior_state, _ = self.transition_model(posterior_state, action.unsqueeze(dim=0), belief,
-                                                                 embedding)
+        belief, _, _, posterior_state, _ = self.transition_model(
+            posterior_state, action.unsqueeze(dim=0), belief, embedding,
+            _noise=None if nz is None else (nz["prior"].unsqueeze(0), nz["post"].unsqueeze(0)))
         belief, posterior_state = belief.squeeze(dim=0), posterior_state.squeeze(dim=0)
-        action, _ = self.get_action(belief, posterior_state)
+        action, _ = self.get_action(belief, posterior_state, _noise=None if nz is None else {
+            "action": nz["action"].unsqueeze(0).contiguous(), "entropy": nz["entropy"].unsqueeze(0).contiguous(),
+            "img_prior": torch.zeros(1, belief.shape[0], self.state_size, device=self.device)})
         if explore:
-            action = torch.clamp(action + self.action_noise * torch.randn_like(action), -1, 1)
+            eps = torch.randn_like(action) if nz is None else nz["explore"]
+            action = torch.clamp(action + self.action_noise * eps, -1, 1)
         batched = hasattr(env, "n") and hasattr(env, "envs")          # EnvBatcher (src/env.py:343)
         next_observation, reward, done = env.step(action.cpu() if batched else action[0].cpu())
         return belief, posterior_state, action, next_observation, reward, done

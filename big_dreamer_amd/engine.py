@@ -12,9 +12,11 @@ become observe/imagine/MLP backward kernels + weight-gradient GEMMs).
 """
 from __future__ import annotations
 
+import collections.abc
 import ctypes as C
 import math
 import os
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -66,11 +68,13 @@ class ParamGroup:
         self.g: Dict[Tuple[str, str], torch.Tensor] = {}
         self.ps: Dict[Tuple[str, str], torch.Tensor] = {}
         self.gs: Dict[Tuple[str, str], torch.Tensor] = {}
+        self._layout: Dict[Tuple[str, str], tuple] = {}
         off = 0
         for mod, name, shape in specs:
             k = int(np.prod(shape))
             perm = conv_storage and len(shape) == 4
             sshape = (shape[0], shape[2], shape[3], shape[1]) if perm else shape
+            self._layout[(mod, name)] = (off, k, sshape, perm)
 
             def views(buf):
                 st = buf[off:off + k].view(sshape)
@@ -80,6 +84,97 @@ class ParamGroup:
             if with_opt:
                 self.gs[(mod, name)], self.g[(mod, name)] = views(self.grad)
             off += k
+
+    def logical(self, buf: torch.Tensor, mod: str, name: str) -> torch.Tensor:
+        """View of `buf` (a flat buffer laid out like `flat`: grad, m, v) with the reference's shape of (mod, name)."""
+        off, k, sshape, perm = self._layout[(mod, name)]
+        st = buf[off:off + k].view(sshape)
+        return st.permute(0, 3, 1, 2) if perm else st
+
+
+def _adam_state_dict(g: ParamGroup, lr: float, hp: dict) -> dict:
+    """The group's optimiser state in torch.optim.Adam's state_dict layout (parameter index = reference parameter
+    order, moments in the reference's logical shapes), so that the reference's ``model_optimizer.load_state_dict``
+    accepts it (src/planet.py:114)."""
+    state = {}
+    for i, (mod, name, _shape) in enumerate(g.specs):
+        state[i] = {"step": torch.tensor(float(g.step)), "exp_avg": g.logical(g.m, mod, name).detach().cpu().clone().contiguous(),
+                    "exp_avg_sq": g.logical(g.v, mod, name).detach().cpu().clone().contiguous()}
+    group = {"lr": lr, "betas": (0.9, 0.999), "eps": hp["adam_epsilon"], "weight_decay": hp["weight_decay"], "amsgrad": False,
+             "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+             "params": list(range(len(g.specs)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def _load_adam_state_dict(g: ParamGroup, sd: dict) -> None:
+    st = sd["state"]
+    if not st:                      # a freshly built optimiser: nothing to restore
+        g.m.zero_(); g.v.zero_(); g.step = 0
+        return
+    assert len(st) == len(g.specs), f"optimizer state has {len(st)} parameters, this group {len(g.specs)}"
+    steps = set()
+    for i, (mod, name, shape) in enumerate(g.specs):
+        e = st[i] if i in st else st[str(i)]
+        assert tuple(e["exp_avg"].shape) == tuple(shape), (mod, name, tuple(e["exp_avg"].shape), shape)
+        g.logical(g.m, mod, name).copy_(e["exp_avg"].to(torch.float32))
+        g.logical(g.v, mod, name).copy_(e["exp_avg_sq"].to(torch.float32))
+        steps.add(int(float(e["step"])))
+    assert len(steps) == 1, f"per-parameter Adam step counts differ: {steps}"
+    g.step = steps.pop()
+
+
+class _LogRecord:
+    """Pinned host copy of the scalar board of ONE train step, filled by three asynchronous D2H copies (one per
+    optimiser phase, each on the stream that wrote the slots) -- reading it never stalls the pipeline streams."""
+
+    ROW = {"model": 0, "actor": 1, "critic": 2}
+
+    def __init__(self):
+        self.host = torch.zeros(3, N_SLOTS + 1, dtype=torch.float32).pin_memory()     # last column: cluster error word
+        self.events: List[Optional[torch.cuda.Event]] = [None, None, None]
+        self.counts: Optional[dict] = None
+        self.owner = None          # weakref to the LazyLogs handed to the caller
+        self.need = (0, 1, 2)
+
+
+class LazyLogs(collections.abc.MutableMapping):
+    """The reference's log dict (src/dreamer.py:293-296,359-360,383), resolved on first read.
+
+    ``Dreamer.train_step`` returns one per step; nothing synchronises until a key is read, so the reference loop's
+    ``for _ in range(collect_interval): logs = model.train_step()`` (src/main.py:105-108) runs the cross-step pipeline
+    and only the burst's last dict -- the one the loop reads -- waits for the GPU.  Keys and values are exactly those
+    of the eager dict; extra keys may be written (``logs["weight_update_per_sec"] = ...``, src/main.py:108)."""
+
+    def __init__(self, eng: "DreamerEngine", rec: _LogRecord, drop_prefix: Tuple[str, ...] = ()):
+        self._eng, self._rec, self._drop = eng, rec, drop_prefix
+        self._vals: Optional[Dict[str, float]] = None
+        self._extra: Dict[str, object] = {}
+
+    def resolve(self) -> Dict[str, float]:
+        if self._vals is None:
+            vals = self._eng._resolve_record(self._rec)
+            self._vals = {k: v for k, v in vals.items() if not k.startswith(self._drop)} if self._drop else vals
+            self._rec = None
+        return self._vals
+
+    def __getitem__(self, k):
+        return self._extra[k] if k in self._extra else self.resolve()[k]
+
+    def __setitem__(self, k, v):
+        self._extra[k] = v
+
+    def __delitem__(self, k):
+        del self._extra[k]
+
+    def __iter__(self):
+        yield from self.resolve()
+        yield from (k for k in self._extra if k not in self._vals)
+
+    def __len__(self):
+        return len(set(self.resolve()) | set(self._extra))
+
+    def __repr__(self):
+        return repr(dict(self.items()))
 
 
 class WgradBatch:
@@ -120,7 +215,13 @@ class WgradBatch:
                 self._cache.pop(next(iter(self._cache)))
             hit = self._cache[key] = (table, n, tb.value, tr.value)
         table, n, tb, tr = hit
-        cabi.check(lib.bd_wgrad_grouped(table.data_ptr(), n, tb, tr, ptr(getattr(eng, self.ws_attr)), cabi.stream()))
+        ws = ptr(getattr(eng, self.ws_attr))
+        if eng._timers_on:       # bracket the slab-GEMM kernel alone (one launch) with HIP events; the reduce follows
+            with eng.span("wgrad_gemm_" + self.name):
+                cabi.check(lib.bd_wgrad_grouped_phase(table.data_ptr(), n, tb, tr, ws, 1, cabi.stream()))
+            cabi.check(lib.bd_wgrad_grouped_phase(table.data_ptr(), n, tb, tr, ws, 2, cabi.stream()))
+        else:
+            cabi.check(lib.bd_wgrad_grouped(table.data_ptr(), n, tb, tr, ws, cabi.stream()))
         self.items = []
 
 
@@ -212,6 +313,9 @@ class DreamerEngine:
             self._main_stream = torch.cuda.Stream(self.dev)
             torch.cuda.set_stream(self._main_stream)
         self._pending_opt: List[tuple] = []
+        self._log_ring: List[_LogRecord] = []
+        self._log_i = 0
+        self._cur_rec: Optional[_LogRecord] = None
         self._wm_done_hist: List[torch.cuda.Event] = []
         self._parity = 0
         self._wgrad_ws_bh = torch.zeros(1, dtype=torch.float32, device=self.dev)
@@ -220,6 +324,7 @@ class DreamerEngine:
         # cluster variant of the observe scan (several CUs per 16-row tile): on unless BD_OBS_CLUSTER=0
         self.use_obs_cluster = os.environ.get("BD_OBS_CLUSTER", "1") != "0"
         self._obs_ws: Optional[torch.Tensor] = None
+        self._obs_err_off: Optional[int] = None
         self._timers_on, self._timer_every, self._timer_tick = False, 1, 0
         self._timer_events: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
         self._build_pack_tables()
@@ -281,6 +386,20 @@ class DreamerEngine:
         for mod, sd in params.items():
             for name, v in sd.items():
                 self.W(mod, name).copy_(torch.as_tensor(np.asarray(v), dtype=torch.float32))
+
+    _OPT = {"model": "model_learning_rate", "actor": "actor_learning_rate", "critic": "value_learning_rate"}
+
+    def optimizer_state_dict(self, group: str) -> dict:
+        """torch.optim.Adam-layout state of one optimiser ("model" | "actor" | "critic"); synchronises."""
+        self.flush_optimizers()
+        self.join()
+        torch.cuda.current_stream().synchronize()
+        return _adam_state_dict(self.groups[group], self.hp[self._OPT[group]], self.hp)
+
+    def load_optimizer_state_dict(self, group: str, sd: dict) -> None:
+        self.flush_optimizers()
+        self.join()
+        _load_adam_state_dict(self.groups[group], sd)
 
     def state_dict(self, mod: str) -> Dict[str, torch.Tensor]:
         g = self.groups[self._mod_group[mod]]
@@ -413,7 +532,10 @@ class DreamerEngine:
     def _allreduce(self, t: torch.Tensor, key: Optional[str] = None) -> None:
         self.dp.allreduce_sum_(t, key)
 
-    def optimizer_step(self, group: str, slot: int, lr: float, red_ws: Optional[torch.Tensor] = None) -> None:
+    def optimizer_step(self, group: str, slot: int, lr: float, red_ws: Optional[torch.Tensor] = None,
+                       rec: Optional[_LogRecord] = None) -> None:
+        """all-reduce (data-parallel) + global-norm clip + Adam + re-pack of one optimiser, on the current stream.
+        `rec`: log record that receives this phase's snapshot of the scalar board (lazy logs)."""
         g = self.groups[group]
         red_ws = self.red_ws if red_ws is None else red_ws
         self._allreduce(g.grad, group)       # grads already carry 1/global-count: SUM over ranks = global-mean gradient
@@ -424,9 +546,63 @@ class DreamerEngine:
                                     hp["adam_epsilon"], hp["weight_decay"], g.step, hp["grad_clip_norm"],
                                     ptr(self.scalars), slot, cabi.stream()))
         self.pack(group)
+        rec = rec if rec is not None else self._cur_rec
+        if rec is not None:
+            self._snapshot(rec, _LogRecord.ROW[group])
+
+    # ------------------------------------------------------------------------------------------ lazy logs
+    def _new_record(self) -> _LogRecord:
+        """Next record of a ring of eight; a record still referenced by an unread LazyLogs is resolved first."""
+        if len(self._log_ring) < 8:
+            self._log_ring.append(_LogRecord())
+            rec = self._log_ring[-1]
+        else:
+            rec = self._log_ring[self._log_i]
+            self._log_i = (self._log_i + 1) % 8
+            owner = rec.owner() if rec.owner is not None else None
+            if owner is not None and owner._vals is None:
+                owner.resolve()
+        rec.events = [None, None, None]
+        rec.owner, rec.counts = None, None
+        return rec
+
+    def _snapshot(self, rec: _LogRecord, row: int) -> None:
+        """Asynchronous D2H of the scalar board (+ the cluster scan's sticky error word) into `rec`, on the current
+        stream, behind the kernels of this phase that wrote its slots."""
+        rec.host[row, :N_SLOTS].copy_(self.scalars, non_blocking=True)
+        if row == 0 and self._obs_ws is not None and self._obs_err_off is not None:
+            rec.host[row, N_SLOTS:].copy_(self._obs_ws[self._obs_err_off:self._obs_err_off + 1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        rec.events[row] = ev
+
+    def _resolve_record(self, rec: _LogRecord) -> Dict[str, float]:
+        self.flush_optimizers()            # data-parallel: the step's actor / critic updates may still be queued on the host
+        for row in rec.need:
+            assert rec.events[row] is not None, "log record read before its step was queued"
+            rec.events[row].synchronize()
+        h = rec.host.numpy()
+        s = h[0, :N_SLOTS].copy()
+        for slot in (SLOT_RET, SLOT_ENT, SLOT_GN_ACTOR):
+            s[slot] = h[1, slot]
+        for slot in (SLOT_VAL, SLOT_GN_CRITIC):
+            s[slot] = h[2, slot]
+        self._raise_on_cluster_error(int(h[0, N_SLOTS:].view(np.uint32)[0]))
+        return self._logs_from(s, rec.counts)
+
+    def _raise_on_cluster_error(self, word: int) -> None:
+        if word:
+            off = self._obs_err_off
+            self._obs_ws[off:off + 1].zero_()                    # reported once
+            which = "+".join(n for b, n in ((1, "forward"), (2, "backward")) if word & b)
+            raise RuntimeError(f"bigdreamer_hip: a member of the cluster observe scan timed out waiting for its peers "
+                               f"({which} scan): the step's posteriors / gradients are wrong (BD_OBS_CLUSTER=0 selects "
+                               "the single-workgroup scan)")
 
     def update_critic(self) -> None:
-        """polyak_update(critic_target, critic, polyak_avg) (src/dreamer.py:423-427)."""
+        """polyak_update(critic_target, critic, polyak_avg) (src/dreamer.py:423-427).  Data-parallel: issues the pending
+        critic update first (a collective -- call on every rank, as src/main.py:110-112 does)."""
+        self.flush_optimizers()
         self.join()
         t, s = self.groups["critic_target"], self.groups["critic"]
         cabi.check(lib.bd_polyak(ptr(t.flat), ptr(s.flat), t.numel, float(self.hp["polyak_avg"]), cabi.stream()))
@@ -528,16 +704,25 @@ class DreamerEngine:
         return feat, qm, qs
 
     def _cluster_ok(self, B: int) -> bool:
-        return self.use_obs_cluster and int(lib.bd_observe_cluster_size(B, self.d.Be)) > 0
+        """Cluster scan only while its tiles*C one-per-CU members leave half the chip to the kernels the other pipeline
+        streams run beside it (members claim a whole CU's LDS and advance in lock step: on a crowded chip they would
+        queue for CUs behind unrelated workgroups); larger batches use the single-workgroup scan (observe.hip)."""
+        if not self.use_obs_cluster:
+            return False
+        C_ = int(lib.bd_observe_cluster_size(B, self.d.Be))
+        return C_ > 0 and ((B + 15) // 16) * C_ <= int(os.environ.get("BD_OBS_CLUSTER_MAX_WGS", "128"))
 
     def _cluster_ws(self, B: int) -> torch.Tensor:
         need = int(lib.bd_observe_cluster_ws_floats(B, self.d.Be))
-        if self._obs_ws is None or self._obs_ws.numel() < need:
-            self._obs_ws = torch.zeros(need, dtype=torch.float32, device=self.dev)
+        off = int(lib.bd_observe_cluster_err_offset(B))
+        if self._obs_ws is None or self._obs_ws.numel() < need or self._obs_err_off != off:
+            self._obs_ws = torch.zeros(need, dtype=torch.float32, device=self.dev)     # zero: flags AND the sticky error word
+            self._obs_err_off = off
         return self._obs_ws
 
     def cluster_status(self, B: int) -> None:
-        """Raise if a member of the last cluster launch timed out waiting for its peers (synchronises)."""
+        """Raise if a member of ANY cluster launch since the last check timed out waiting for its peers (synchronises;
+        the error word is sticky across launches and cleared by this read)."""
         if self._obs_ws is not None:
             cabi.check(lib.bd_observe_cluster_status(ptr(self._obs_ws), B, cabi.stream()))
 
@@ -711,22 +896,30 @@ class DreamerEngine:
         front of the KL / world-model all-reduces of step k+1 and stall dynamics learning k+1 half-way.  Deferred, the
         order per host step is kl, model (k+1), actor, critic (k): each is ready by the time its turn comes."""
         if self.pipeline and self.defer_opt:
-            self._pending_opt.append((span, group, slot, lr, red_ws, torch.cuda.current_stream()))
+            self._pending_opt.append((span, group, slot, lr, red_ws, torch.cuda.current_stream(), self._cur_rec))
             return
         with self.span(span):
             self.optimizer_step(group, slot, lr, red_ws)
 
-    def _flush_pending_opt(self) -> None:
+    def flush_optimizers(self) -> None:
+        """Issue the actor / critic optimiser steps the data-parallel schedule holds back by one host step.  They contain
+        the gradient all-reduces, i.e. this is a COLLECTIVE: it runs inside train_step, logs() (also when a lazy log dict
+        is read), update_critic() and update_belief_and_act(), which every rank calls at the same points of the
+        collect-update loop (src/main.py:103-143).  join() and the modules' forward() never issue collectives, so a call
+        only one rank makes (e.g. rank 0 rendering a video with observation_model, src/main.py:244) cannot reorder the
+        ranks' collectives on the shared communicator."""
         pend, self._pending_opt = self._pending_opt, []
-        for span, group, slot, lr, red_ws, stream in pend:
+        for span, group, slot, lr, red_ws, stream, rec in pend:
             with torch.cuda.stream(stream):
                 with self.span(span):
-                    self.optimizer_step(group, slot, lr, red_ws)
+                    self.optimizer_step(group, slot, lr, red_ws, rec)
+
+    _flush_pending_opt = flush_optimizers
 
     def join(self) -> None:
-        """Order everything the pipeline streams have been given before later work on the caller's stream."""
+        """Order everything the pipeline streams have been given before later work on the caller's stream (stream
+        ordering only: no host synchronisation, no collectives)."""
         if self.pipeline:
-            self._flush_pending_opt()
             cur = torch.cuda.current_stream()
             cur.wait_stream(self._s_wm)
             cur.wait_stream(self._s_bh)
@@ -743,12 +936,14 @@ class DreamerEngine:
         obs = batch["observations"]
         B = obs.shape[1]
         self._timer_tick += 1
+        lazy = sync_logs == "lazy"
+        rec = self._cur_rec = self._new_record() if lazy else None
         if not self.pipeline:
             if noise is None:
                 noise = self.make_noise(B)
             feat = self._dynamics_phase(batch, noise, "")
             self._behaviour_phase(feat, noise, obs.shape[0] - 1, B, self.red_ws, None)
-            return self.logs() if sync_logs else {}
+            return self._finish_step(rec, sync_logs)
         cur = torch.cuda.current_stream()
         s_wm, s_bh = self._s_wm, self._s_bh
         par = self._parity
@@ -782,11 +977,21 @@ class DreamerEngine:
             self._behaviour_phase(feat, nz, obs.shape[0] - 1, B, self.red_ws_bh, par)
             self._ev_bh_done[par] = torch.cuda.Event()
             self._ev_bh_done[par].record(s_bh)
+        return self._finish_step(rec, sync_logs)
+
+    def _finish_step(self, rec: Optional[_LogRecord], sync_logs):
+        if rec is not None:                      # sync_logs == "lazy"
+            rec.counts = dict(self._counts)
+            self._cur_rec = None
+            out = LazyLogs(self, rec)
+            rec.owner = weakref.ref(out)
+            return out
         return self.logs() if sync_logs else {}
 
     def world_model_step(self, batch: Dict[str, torch.Tensor], noise: Optional[Dict[str, torch.Tensor]] = None,
                          sync_logs: bool = True) -> Dict[str, float]:
         """Planet.train_step (src/planet.py:310-368): dynamics learning only, on the caller's stream."""
+        self.flush_optimizers()
         self.join()
         obs = batch["observations"]
         T, B = obs.shape[0] - 1, obs.shape[1]
@@ -1076,9 +1281,18 @@ class DreamerEngine:
     def logs(self) -> Dict[str, float]:
         """One D2H copy of the scalar board -> the reference's log dict (src/dreamer.py:293-296,359-360,383).
         Values are this rank's shard means (fp32 arithmetic as in the reference)."""
+        self.flush_optimizers()
         self.join()
-        s = self.scalars.cpu().numpy().astype(np.float32)
-        hp, c = self.hp, self._counts
+        if self._obs_ws is not None and self._obs_err_off is not None:
+            both = torch.cat([self.scalars, self._obs_ws[self._obs_err_off:self._obs_err_off + 1]]).cpu().numpy()
+            self._raise_on_cluster_error(int(both[N_SLOTS:].view(np.uint32)[0]))
+            s = both[:N_SLOTS].astype(np.float32)
+        else:
+            s = self.scalars.cpu().numpy().astype(np.float32)
+        return self._logs_from(s, self._counts)
+
+    def _logs_from(self, s: np.ndarray, c: dict) -> Dict[str, float]:
+        hp = self.hp
         f32 = np.float32
         N, Mi = f32(c["N"]), f32(c["Mi"])
         obs, rew = s[SLOT_OBS] / N, s[SLOT_REW] / N

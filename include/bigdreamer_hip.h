@@ -121,6 +121,10 @@ typedef struct {
 int bd_wgrad_plan(bd_wgrad_desc* descs_host, int n, int* total_blocks, int* total_red_blocks, size_t* ws_floats);
 int bd_wgrad_grouped(const bd_wgrad_desc* descs_dev, int n, int total_blocks, int total_red_blocks, float* ws,
                      void* stream);
+/* The two launches of bd_wgrad_grouped separately (phase 1: the slab GEMM kernel; phase 2: the fixed-order reduce), so
+ * that a benchmark can bracket the GEMM kernel alone with HIP events.  phase 0 = both = bd_wgrad_grouped. */
+int bd_wgrad_grouped_phase(const bd_wgrad_desc* descs_dev, int n, int total_blocks, int total_red_blocks, float* ws,
+                           int phase, void* stream);
 
 /* ---- conv stacks of the pixel configurations (CnnImageEncoder src/models.py:527-564, ObservationModel
  * src/models.py:319-362; F.conv2d / F.conv_transpose2d and their autograd backward) as gather-GEMMs on NHWC images:
@@ -225,13 +229,22 @@ int bd_observe_backward(const bd_observe_bwd_args* a, void* stream);
  * workgroups (CUs) share each 16-row tile.  The GRU contraction is split by output column blocks over the members,
  * everything small is computed redundantly, and one all-gather per time step goes through `ws` (write-through
  * stores + per-member flags + sc1 loads, bounded spins).  Same arguments and results as bd_observe_forward /
- * bd_observe_backward; `ws` holds bd_observe_cluster_ws_floats(B, Be) floats and is zeroed (flags) by a memset
- * node on `stream` ahead of each launch.  bd_observe_cluster_status synchronises and reports a peer time-out. */
+ * bd_observe_backward; `ws` holds bd_observe_cluster_ws_floats(B, Be) floats, is zero-filled ONCE by the caller when
+ * it is allocated, and its flags are zeroed by a memset node on `stream` ahead of each launch.  The error word inside
+ * it (float index bd_observe_cluster_err_offset(B), a u32) is STICKY: a member that times out waiting for its peers
+ * ORs 1 (forward) / 2 (backward) into it, launches never clear it, so a time-out of any launch stays visible until
+ * bd_observe_cluster_status reads it.  bd_observe_cluster_status synchronises `stream`, returns non-zero with the
+ * error text if the word is set, and clears it.  A host that already copies results back every step (the engine's
+ * log fetch) reads the word in the same transfer instead.  bd_observe_cluster_set_spin_limit (0 = default, about
+ * seconds) exists so that tests can force a time-out.  The launches return an error (never abort the queue) when the
+ * kernel's static + dynamic LDS would exceed the CU's 160 KiB. */
 int bd_observe_cluster_size(int B, int Be);   /* workgroups per 16-row tile; 0 = use bd_observe_forward/backward */
 size_t bd_observe_cluster_ws_floats(int B, int Be);
 int bd_observe_forward_cluster(const bd_observe_fwd_args* a, float* ws, size_t ws_floats, void* stream);
 int bd_observe_backward_cluster(const bd_observe_bwd_args* a, float* ws, size_t ws_floats, void* stream);
-int bd_observe_cluster_status(const float* ws, int B, void* stream);
+int bd_observe_cluster_status(float* ws, int B, void* stream);
+size_t bd_observe_cluster_err_offset(int B);
+int bd_observe_cluster_set_spin_limit(unsigned limit);   /* returns 0 */
 
 /* GaussianBeliefModel tail (src/models.py:70-73): out[M x 2S] -> mean, std=softplus(raw)+min_std,
  * state = mean + std*eps.  Used for the batched prior of the observe scan. */

@@ -382,6 +382,49 @@ def run_action_mode(dreamer_mod, d: synth.Dims, seed: int):
     print(f"wrote {path}")
 
 
+def run_act(dreamer_mod):
+    """Planet.update_belief_and_act (src/planet.py:370-403) through Dreamer.get_action (src/dreamer.py:429-444): three
+    consecutive calls (the carried belief / posterior state / action feed the next call) at B=1 (collection, explore=True)
+    and B=10 (evaluation with an EnvBatcher-like env, explore=False), config-2 model size, injected noise.
+    RNG order per call: prior (B,S), posterior (B,S), action (B,A), entropy (100,B,A), [explore: (B,A)]."""
+    import env as ref_env
+    d = synth.CONFIG2
+    out = {}
+    for name, B, explore, seed in (("b1_explore", 1, True, 31), ("b10_eval", 10, False, 32)):
+        P = synth.make_params(d, seed)
+        agent = build_agent(dreamer_mod, d, P)
+        rng = np.random.Generator(np.random.PCG64(seed + 300))
+        obs_seq = rng.standard_normal((3, B, d.O), dtype=np.float32)
+
+        class Env(ref_env.EnvBatcher if B > 1 else object):      # isinstance(env, EnvBatcher) picks action vs action[0]
+            def __init__(self):
+                self.got = []
+
+            def step(self, a):
+                self.got.append(t2n(a))
+                return None, 0.0, False
+
+        env = Env()
+        belief, state = torch.zeros(B, d.Be), torch.zeros(B, d.S)
+        action = torch.zeros(B, d.A)
+        ns = synth.NoiseStream(seed)
+        with torch.no_grad(), Inject(ns):
+            for i in range(3):
+                belief, state, action, _, _, _ = agent.update_belief_and_act(env, belief, state, action,
+                                                                            torch.from_numpy(obs_seq[i]), explore=explore)
+                out[f"{name}.belief{i}"], out[f"{name}.state{i}"], out[f"{name}.action{i}"] = t2n(belief), t2n(state), t2n(action)
+                out[f"{name}.env_action{i}"] = env.got[-1]
+        want = []
+        for i in range(3):
+            want += [(B, d.S), (B, d.S), (B, d.A), (d.n_entropy, B, d.A)] + ([(B, d.A)] if explore else [])
+        assert ns.calls == want, ns.calls
+        out[f"{name}.obs"] = obs_seq
+        out[f"{name}.meta"] = np.array([B, int(explore), seed])
+    path = os.path.join(ROOT, "tests", "golden", "act.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
 def main_planner(dreamer_mod):
     run_planner(dreamer_mod, "planner_tiny", synth.TINY, B=2, horizon=5, iters=4, candidates=64, top=8, seed=6, full=True)
     # the reference's defaults (conf/config.yaml:31,63-66) at the config-2 model size, one environment
@@ -407,11 +450,20 @@ def main():
     run_pixel_preprocess()
     run_config(dreamer_mod, "config1", synth.CONFIG1, full=False)
     run_config(dreamer_mod, "config2", synth.CONFIG2, full=False)
+    run_config(dreamer_mod, "config3", synth.CONFIG3, full=False, seed=6)      # BASELINE configs[2], full size (~1 min)
     main_planner(dreamer_mod)
+    run_act(dreamer_mod)
 
 
 if __name__ == "__main__":
-    if "--planner-only" in sys.argv:       # regenerate only the planner / PlaNet vectors
+    if "--only" in sys.argv:               # regenerate single files: --only config3 act ...
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        dm, mm = _import_reference()
+        for what in sys.argv[sys.argv.index("--only") + 1:]:
+            {"config3": lambda: run_config(dm, "config3", synth.CONFIG3, full=False, seed=6),
+             "act": lambda: run_act(dm)}[what]()
+    elif "--planner-only" in sys.argv:       # regenerate only the planner / PlaNet vectors
         torch.manual_seed(0)
         torch.set_num_threads(8)
         main_planner(_import_reference()[0])

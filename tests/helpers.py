@@ -17,6 +17,7 @@ CASES = {
     "tiny_pixel_lin": (synth.TINY_PIXEL_LIN, 5, {}, False),
     "config1": (synth.CONFIG1, 0, {}, False),
     "config2": (synth.CONFIG2, 0, {}, False),
+    "config3": (synth.CONFIG3, 6, {}, False),       # BASELINE configs[2] at full size: 64x64 pixels, A=17, batch 50 x chunk 50
 }
 
 

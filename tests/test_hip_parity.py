@@ -97,7 +97,8 @@ def test_forward_pieces_vs_oracle(name):
                                           ("config1", True), ("config2", True), ("small", False),
                                           ("tiny_freenats0", False), ("config2", False),
                                           ("tiny_pixel", True), ("tiny_pixel_lin", True),
-                                          ("tiny_pixel", "miopen"), ("tiny_pixel_lin", "miopen")])
+                                          ("tiny_pixel", "miopen"), ("tiny_pixel_lin", "miopen"),
+                                          ("config3", True)])
 def test_train_steps_vs_oracle_and_golden(name, cluster, monkeypatch):
     """Two whole train steps: losses, clipped gradients, gradient norms, post-Adam weights -- with the observe
     scan run by the multi-CU cluster kernels (default) and by the single-workgroup kernels."""
