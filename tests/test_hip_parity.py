@@ -194,10 +194,12 @@ def test_wide_action_vectors_vs_oracle(dims):
         print("\n".join(rep[-80:]))
 
 
-def test_wide_batch_uses_two_column_blocks_per_cluster_member():
+def test_wide_batch_uses_two_column_blocks_per_cluster_member(monkeypatch):
     """B = 320 sequences = 20 row tiles: 20 x 13 single-block members would not be co-resident on 256 CUs, so the observe
     scans run with 7 members per tile owning two GRU column blocks each (observe_cluster.hip, pick_cluster).  One whole
-    train step at the config-2 model size against the oracle (no golden file at this batch size)."""
+    train step at the config-2 model size against the oracle (no golden file at this batch size).  (140 members are
+    above the engine's default cap of half the chip for the cluster scan: lifted here to exercise the kernel form.)"""
+    monkeypatch.setenv("BD_OBS_CLUSTER_MAX_WGS", "256")
     from big_dreamer_amd import _cabi as cabi
     from big_dreamer_amd.engine import DreamerEngine
     from oracle import dreamer_oracle as O
