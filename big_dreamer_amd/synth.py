@@ -32,6 +32,21 @@ class Dims:
     O: int = 3       # observation_size (Pendulum 3, state observations)
     n_entropy: int = 100  # SampleDist samples (src/models.py:681)
     pixel: bool = False   # 64x64x3 pixel observations (conv encoder / decoder, src/models.py:319-362,527-564)
+    cat_D: int = 0        # latent_distribution="Categorical": discrete_latent_dimensions (0 = Gaussian latents)
+    cat_C: int = 0        #                                    discrete_latent_classes; S must equal cat_D * cat_C (src/planet.py:56-57)
+
+    def __post_init__(self):
+        assert (self.cat_D == 0) == (self.cat_C == 0) and (self.cat_D == 0 or self.S == self.cat_D * self.cat_C), \
+            "Categorical latents: state_size = discrete_latent_dimensions * discrete_latent_classes"
+
+    @property
+    def categorical(self) -> bool:
+        return self.cat_D > 0
+
+    @property
+    def head_out(self) -> int:
+        """Output width of belief_prior / belief_posterior: (mean, raw std) or D*C logits (src/models.py:44-117)."""
+        return self.S if self.cat_D else 2 * self.S
 
     @property
     def T(self) -> int:
@@ -59,6 +74,11 @@ TINY_PIXEL = Dims(B=2, L=4, H=3, Be=24, S=6, Hd=20, E=1024, A=2, O=12288, pixel=
 TINY_PIXEL_LIN = Dims(B=2, L=3, H=3, Be=20, S=5, Hd=24, E=48, A=1, O=12288, pixel=True)     # Linear(1024, E) tail
 CONFIG3 = Dims(A=17, O=12288, pixel=True)                                                   # BASELINE.json configs[2]
 SMALL = Dims(B=7, L=9, H=6, Be=48, S=10, Hd=36, E=72, A=3, O=4, n_entropy=100)
+# Categorical latents (algorithm=dreamerV2 latent_distribution=Categorical): ragged factors, then the reference's 32 x 32
+CAT_TINY = Dims(B=3, L=5, H=4, Be=24, S=15, Hd=20, E=40, A=2, O=5, cat_D=3, cat_C=5)
+CAT_32 = Dims(B=18, L=6, H=5, Be=64, S=1024, Hd=48, E=96, A=3, O=6, cat_D=32, cat_C=32)       # 32 x 32 latents, two row tiles
+CONFIG5 = Dims(B=100, A=17, O=12288, pixel=True, S=1024, cat_D=32, cat_C=32)   # BASELINE configs[4] per GPU: batch 800 / 8
+CONFIG5_STATE = Dims(B=100, S=1024, cat_D=32, cat_C=32)                         # same latents on state observations
 
 DENSE_LAYERS = 4  # DenseModel / ActorModel n_layers (src/models.py:378,482)
 
@@ -83,12 +103,12 @@ def param_shapes(d: Dims) -> Dict[str, List[Tuple[str, Tuple[int, ...]]]]:
         ("fc_embed_state_action.0.bias", (d.Be,)),
         ("belief_prior.model.0.weight", (d.Hd, d.Be)),
         ("belief_prior.model.0.bias", (d.Hd,)),
-        ("belief_prior.model.2.weight", (2 * d.S, d.Hd)),
-        ("belief_prior.model.2.bias", (2 * d.S,)),
+        ("belief_prior.model.2.weight", (d.head_out, d.Hd)),
+        ("belief_prior.model.2.bias", (d.head_out,)),
         ("belief_posterior.model.0.weight", (d.Hd, d.Be + d.E)),
         ("belief_posterior.model.0.bias", (d.Hd,)),
-        ("belief_posterior.model.2.weight", (2 * d.S, d.Hd)),
-        ("belief_posterior.model.2.bias", (2 * d.S,)),
+        ("belief_posterior.model.2.weight", (d.head_out, d.Hd)),
+        ("belief_posterior.model.2.bias", (d.head_out,)),
     ]
     feat = d.Be + d.S
     hid = [d.Hd] * DENSE_LAYERS
@@ -191,6 +211,12 @@ class NoiseStream:
         self.calls.append(shape)
         return self.rng.standard_normal(shape, dtype=np.float32)
 
+    def exponential(self, shape) -> np.ndarray:
+        """Exp(1) draws: what torch.multinomial's single-draw path consumes per class (q; sample = argmax(probs / q))."""
+        shape = tuple(int(s) for s in shape)
+        self.calls.append(("exp",) + shape)
+        return self.rng.standard_exponential(shape, dtype=np.float32)
+
 
 def make_noise(d: Dims, seed: int = 0) -> Dict[str, np.ndarray]:
     """All noise of one train_step, drawn in reference order:
@@ -198,18 +224,22 @@ def make_noise(d: Dims, seed: int = 0) -> Dict[str, np.ndarray]:
     for t<H': action (N,A), entropy (100,N,A) (src/dreamer.py:443-444), prior (N,S) (src/dreamer.py:223).
     """
     ns = NoiseStream(seed)
+    # Categorical latents: the state draws are the Exp(1) variates of the sampler, one per class, viewed (rows*D, C) as
+    # OneHotCategorical.sample hands them to torch.multinomial; stored (.., rows, D*C)
+    state_draw = (lambda rows: ns.exponential((rows * d.cat_D, d.cat_C)).reshape(rows, d.S)) if d.categorical else \
+        (lambda rows: ns.normal((rows, d.S)))
     obs_prior = np.empty((d.T, d.B, d.S), np.float32)
     obs_post = np.empty((d.T, d.B, d.S), np.float32)
     for t in range(d.T):
-        obs_prior[t] = ns.normal((d.B, d.S))
-        obs_post[t] = ns.normal((d.B, d.S))
+        obs_prior[t] = state_draw(d.B)
+        obs_post[t] = state_draw(d.B)
     act = np.empty((d.Hm, d.N, d.A), np.float32)
     ent = np.empty((d.Hm, d.n_entropy, d.N, d.A), np.float32)
     img = np.empty((d.Hm, d.N, d.S), np.float32)
     for t in range(d.Hm):
         act[t] = ns.normal((d.N, d.A))
         ent[t] = ns.normal((d.n_entropy, d.N, d.A))
-        img[t] = ns.normal((d.N, d.S))
+        img[t] = state_draw(d.N)
     return {"obs_prior": obs_prior, "obs_post": obs_post, "action": act, "entropy": ent,
             "img_prior": img}
 

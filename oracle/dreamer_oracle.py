@@ -100,10 +100,15 @@ def gaussian_belief(inp: Tensor, sd: Dict[str, Tensor], which: str, eps: Tensor,
 # ----------------------------------------------------------------------------------------------
 def transition_forward(sd: Dict[str, Tensor], init_state: Tensor, actions: Tensor, init_belief: Tensor,
                        embeddings: Optional[Tensor], nonterminals: Optional[Tensor],
-                       eps_prior: Tensor, eps_post: Optional[Tensor]):
+                       eps_prior: Tensor, eps_post: Optional[Tensor], cat: Optional[Tuple[int, int]] = None):
     """Returns beliefs, prior_states, (prior_means, prior_stds), posterior_states,
     (posterior_means, posterior_stds); posterior entries are None when embeddings is None
-    (src/models.py:296-297).  ``actions``/``embeddings``/``nonterminals`` have T entries."""
+    (src/models.py:296-297).  ``actions``/``embeddings``/``nonterminals`` have T entries.
+    ``cat=(D, C)``: latent_distribution="Categorical" -- the params are 1-tuples ``(logits (T,B,D,C),)`` and the noise
+    holds the sampler's Exp(1) draws (see transition_forward_categorical)."""
+    if cat is not None:
+        return transition_forward_categorical(sd, init_state, actions, init_belief, embeddings, nonterminals, eps_prior,
+                                              eps_post, cat[0], cat[1])
     T = actions.size(0)
     belief, prior_state, post_state = init_belief, init_state, init_state
     beliefs, priors, pmeans, pstds, posts, qmeans, qstds = [], [], [], [], [], [], []
@@ -124,6 +129,40 @@ def transition_forward(sd: Dict[str, Tensor], init_state: Tensor, actions: Tenso
     if embeddings is None:
         return st(beliefs), st(priors), (st(pmeans), st(pstds)), None, None
     return st(beliefs), st(priors), (st(pmeans), st(pstds)), st(posts), (st(qmeans), st(qstds))
+
+
+def _sub(sd: Dict[str, Tensor], which: str) -> Dict[str, Tensor]:
+    return {k[len(which) + 1:]: v for k, v in sd.items() if k.startswith(which + ".")}
+
+
+def transition_forward_categorical(sd, init_state, actions, init_belief, embeddings, nonterminals, q_prior, q_post,
+                                   D: int, C: int):
+    """TransitionModel.forward with latent_distribution="Categorical" (src/models.py:191-299, Categorical branches
+    :226-228,258-260,269-271,283-295) as the reference INTENDS it: at HEAD the loop stores the 1-tuple ``(logits,)`` in
+    the per-step lists (:259-260,270-271), so ``stack`` raises, and ``posterior_params`` loses its tuple (:295).  Here
+    the logits are stored and both params are 1-tuples.  The golden vectors for this path come from the reference's own
+    code run with exactly those two repairs (oracle/gen_golden.py, ``_categorical_shims``).
+    q_prior / q_post: (T, B, D*C) Exp(1) draws of the sampler (categorical_belief)."""
+    T = actions.size(0)
+    belief, prior_state, post_state = init_belief, init_state, init_state
+    beliefs, priors, plog, posts, qlog = [], [], [], [], []
+    prior_sd, post_sd = _sub(sd, "belief_prior"), _sub(sd, "belief_posterior")
+    for t in range(T):
+        state = prior_state if embeddings is None else post_state            # :241
+        if nonterminals is not None:
+            state = state * nonterminals[t]                                   # :247
+        hidden = embed_state_action(state, actions[t], sd)                    # :251
+        belief = gru_cell(hidden, belief, sd)                                 # :252
+        prior_state, (pl,) = categorical_belief(belief, prior_sd, q_prior[t].reshape(-1, D, C), D, C)   # :256
+        beliefs.append(belief); priors.append(prior_state); plog.append(pl)
+        if embeddings is not None:
+            post_in = torch.cat([belief, embeddings[t]], dim=1)               # :265-266
+            post_state, (ql,) = categorical_belief(post_in, post_sd, q_post[t].reshape(-1, D, C), D, C)   # :267
+            posts.append(post_state); qlog.append(ql)
+    st = lambda xs: torch.stack(xs, dim=0)
+    if embeddings is None:
+        return st(beliefs), st(priors), (st(plog),), None, None
+    return st(beliefs), st(priors), (st(plog),), st(posts), (st(qlog),)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -183,19 +222,28 @@ def get_action_mode(belief: Tensor, state: Tensor, sd: Dict[str, Tensor], eps_mo
 # R4: imagine_ahead (src/dreamer.py:179-237)
 # ----------------------------------------------------------------------------------------------
 def imagine_ahead(P, prev_state: Tensor, prev_belief: Tensor, horizon: int, eps_action: Tensor,
-                  eps_entropy: Tensor, eps_prior: Tensor):
-    """Returns beliefs (H',N,Be), prior_states (H',N,S), (means, stds), action_entropy (H',N)."""
+                  eps_entropy: Tensor, eps_prior: Tensor, cat: Optional[Tuple[int, int]] = None):
+    """Returns beliefs (H',N,Be), prior_states (H',N,S), (means, stds), action_entropy (H',N).
+    ``cat=(D, C)``: Categorical latents (src/dreamer.py:205-206,224-227,234-235 with the tuple repaired as in
+    transition_forward_categorical): params = (logits (H',N,D,C),), eps_prior = the sampler's Exp(1) draws (H',N,D*C)."""
     tm = P["transition_model"]
     belief = prev_belief.reshape(-1, prev_belief.size(-1))
     state = prev_state.reshape(-1, prev_state.size(-1))
     bs, ss, ms, sds, ents = [], [], [], [], []
+    prior_sd = _sub(tm, "belief_prior") if cat is not None else None
     for t in range(horizon - 1):
         action, ent = get_action(belief.detach(), state.detach(), P["actor"], eps_action[t], eps_entropy[t])
         hidden = embed_state_action(state, action, tm)
         belief = gru_cell(hidden, belief, tm)
-        state, m, s = gaussian_belief(belief, tm, "belief_prior", eps_prior[t])
+        if cat is not None:
+            state, (m,) = categorical_belief(belief, prior_sd, eps_prior[t].reshape(-1, cat[0], cat[1]), cat[0], cat[1])
+            s = m
+        else:
+            state, m, s = gaussian_belief(belief, tm, "belief_prior", eps_prior[t])
         bs.append(belief); ss.append(state); ms.append(m); sds.append(s); ents.append(ent)
     st = lambda xs: torch.stack(xs, dim=0)
+    if cat is not None:
+        return st(bs), st(ss), (st(ms),), st(ents)
     return st(bs), st(ss), (st(ms), st(sds)), st(ents)
 
 
@@ -372,6 +420,8 @@ class OracleDreamer:
         self.hp = dict(DEFAULT_HP)
         if hp:
             self.hp.update(hp)
+        # latent_distribution="Categorical": hp["categorical"] = (discrete_latent_dimensions, discrete_latent_classes)
+        self.cat = tuple(self.hp["categorical"]) if self.hp.get("categorical") else None
         self.P = {mod: {k: torch.tensor(v, dtype=torch.float32, requires_grad=(mod != "critic_target"))
                         for k, v in sd.items()} for mod, sd in P_numpy.items()}
         self.model_params = [p for mod in MODEL_MODULES for p in self.P[mod].values()]
@@ -393,20 +443,26 @@ class OracleDreamer:
         obs, actions, rewards, nonterm = (batch[k] for k in ("observations", "actions", "rewards", "nonterminals"))
         B = obs.size(1)
         Be = P["transition_model"]["rnn.weight_hh"].size(1)
-        S = P["transition_model"]["belief_prior.model.2.weight"].size(0) // 2
+        S = P["transition_model"]["belief_prior.model.2.weight"].size(0) // (1 if self.cat else 2)
         init_belief = torch.zeros(B, Be)
         init_state = torch.zeros(B, S)
         pixel = obs.dim() == 5
         emb = cnn_encoder(obs[1:], P["encoder"]) if pixel else mlp(obs[1:], P["encoder"])      # :270
         beliefs, prior_states, prior_params, post_states, post_params = transition_forward(
             P["transition_model"], init_state, actions[:-1], init_belief, emb, nonterm[:-1],
-            noise["obs_prior"], noise["obs_post"])                                             # :272-278
+            noise["obs_prior"], noise["obs_post"], self.cat)                                   # :272-278
         if pixel:   # Independent(Normal(means, 1), 3) (src/planet.py:264-265)
             obs_loss = normal_nll_mean(cnn_decoder(beliefs, post_states, P["observation_model"]), obs[1:], event_dims=3)
         else:
             obs_loss = normal_nll_mean(dense_on_features(beliefs, post_states, P["observation_model"]), obs[1:])
         rew_pred = dense_on_features(beliefs, post_states, P["reward_model"])
         rew_loss = normal_nll_mean(rew_pred, rewards[:-1].unsqueeze(-1))
+        if self.cat:
+            kl = kl_loss_categorical(post_params[0], prior_params[0], hp["kl_balance"], hp["free_nats"])
+            model_loss = obs_loss + rew_loss + kl * hp["kl_loss_weight"]                       # :285
+            inter = dict(embeddings=emb, beliefs=beliefs, prior_states=prior_states, prior_logits=prior_params[0],
+                         posterior_states=post_states, posterior_logits=post_params[0], reward_pred=rew_pred)
+            return model_loss, obs_loss, rew_loss, kl, inter
         kl = kl_loss(post_params, prior_params, hp["kl_balance"], hp["free_nats"])
         model_loss = obs_loss + rew_loss + kl * hp["kl_loss_weight"]                           # :285
         inter = dict(embeddings=emb, beliefs=beliefs, prior_states=prior_states, prior_means=prior_params[0],
@@ -459,7 +515,7 @@ class OracleDreamer:
         for mod in MODEL_MODULES + ("critic_target",):
             Pf[mod] = {k: v.detach() for k, v in P[mod].items()}
         img_b, img_s, _, ent = imagine_ahead(Pf, post_states, beliefs, hp["planning_horizon"], noise["action"],
-                                             noise["entropy"], noise["img_prior"])
+                                             noise["entropy"], noise["img_prior"], self.cat)
         img_reward = dense_on_features(img_b, img_s, Pf["reward_model"])                      # :321
         value_pred = dense_on_features(img_b, img_s, Pf["critic_target"])                     # :322
         returns = lambda_return(img_reward, value_pred, value_pred[-1], hp["discount"], hp["disclam"])

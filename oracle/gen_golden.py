@@ -96,7 +96,70 @@ class Inject:
         torch.randn_like, tdn._standard_normal, torch.randn = self._rl, self._sn, self._rn
 
 
+class CategoricalShims:
+    """The two repairs without which the reference cannot run latent_distribution="Categorical" at HEAD (SURVEY.md
+    section 8c), applied AROUND its code -- no control flow of the reference is restated:
+      1. ``stack`` (src/utils.py:36-43, imported by name into models.py and dreamer.py) is handed lists whose entries are
+         the 1-tuples ``(logits,)`` that ``TransitionModel.forward`` (src/models.py:259-260,270-271) and
+         ``Dreamer.imagine_ahead`` (src/dreamer.py:224-227) store: the shim unwraps them before ``torch.stack``.
+      2. ``TransitionModel.forward`` returns ``posterior_params = (stack(...))`` -- parentheses, not a tuple
+         (src/models.py:295) -- which ``_get_dist`` then cannot unpack: the wrapper returns ``(tensor,)``.
+    Sampling: ``OneHotCategoricalStraightThrough.rsample`` reaches ``torch.multinomial(probs, 1, True)``, whose draws
+    happen inside ATen.  Its single-draw algorithm is ``q = empty_like(probs).exponential_(1); argmax(probs / q)``; the
+    shim computes exactly that with q taken from the injected NoiseStream, after checking on the live call (same probs,
+    re-seeded generator) that the formula reproduces the library's sample."""
+
+    def __init__(self, stream: synth.NoiseStream):
+        self.s = stream
+        self.checked = 0
+
+    def __enter__(self):
+        import dreamer as ref_dreamer
+        import models as ref_models
+        self._stack_m, self._stack_d = ref_models.stack, ref_dreamer.stack
+        self._fwd, self._mn = ref_models.TransitionModel.forward, torch.multinomial
+
+        def stack(x):
+            return torch.stack([e[0] if isinstance(e, tuple) else e for e in x[1:]], dim=0)
+
+        fwd = self._fwd
+
+        def forward(self_, *a, **kw):
+            out = fwd(self_, *a, **kw)
+            if out[4] is not None and not isinstance(out[4], tuple):
+                out = out[:4] + ((out[4],),)
+            return out
+
+        real_mn = self._mn
+
+        def multinomial(probs, num_samples, replacement=False, **kw):
+            assert num_samples == 1 and probs.dim() == 2
+            if self.checked < 3:       # the formula IS the library's draw: same probs, same generator state
+                torch.manual_seed(1234 + self.checked)
+                q_lib = torch.empty_like(probs).exponential_(1)
+                torch.manual_seed(1234 + self.checked)
+                assert torch.equal(real_mn(probs, 1, True), (probs / q_lib).argmax(-1, keepdim=True))
+                self.checked += 1
+            q = torch.from_numpy(self.s.exponential(probs.shape))
+            return (probs / q).argmax(-1, keepdim=True)
+
+        ref_models.stack = ref_dreamer.stack = stack
+        ref_models.TransitionModel.forward = forward
+        torch.multinomial = multinomial
+        return self
+
+    def __exit__(self, *a):
+        import dreamer as ref_dreamer
+        import models as ref_models
+        ref_models.stack, ref_dreamer.stack = self._stack_m, self._stack_d
+        ref_models.TransitionModel.forward = self._fwd
+        torch.multinomial = self._mn
+
+
 def build_agent(dreamer_mod, d, P, **over):
+    if d.categorical:
+        over = dict(latent_distribution="Categorical", discrete_latent_dimensions=d.cat_D,
+                    discrete_latent_classes=d.cat_C, **over)
     agent = dreamer_mod.Dreamer(ref_params(d, **over), FakeEnv(d))
     for mod in ("transition_model", "observation_model", "reward_model", "encoder", "actor", "critic",
                 "critic_target"):
@@ -206,6 +269,97 @@ def run_config(dreamer_mod, name: str, d: synth.Dims, full: bool, seed: int = 0,
     path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def run_config_categorical(dreamer_mod, name: str, d: synth.Dims, seed: int, **over):
+    """latent_distribution="Categorical": the reference's own Dreamer code (TransitionModel.forward, _kl_loss Categorical
+    branch, imagine_ahead, train_step x2) under CategoricalShims.  The tiny cases are stored in full, the 32 x 32 ones as
+    sums + strided samples (`store`)."""
+    full = d.S <= 64
+    assert d.categorical
+    out = {}
+    P = synth.make_params(d, seed)
+    batch = synth.make_batch(d, seed)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    agent = build_agent(dreamer_mod, d, P, **over)
+    assert agent.state_size == d.S and agent.latent_distribution == "Categorical"
+    ns = synth.NoiseStream(seed)
+    with Inject(ns), CategoricalShims(ns) as shims:
+        emb = agent.encoder(tb["observations"][1:])
+        beliefs, prior_states, prior_params, post_states, post_params = agent.transition_model(
+            torch.zeros(d.B, d.S), tb["actions"][:-1], torch.zeros(d.B, d.Be), emb, tb["nonterminals"][:-1])
+        obs_loss = agent._observation_loss(beliefs, post_states, tb["observations"][1:])
+        rew_loss = agent._reward_loss(beliefs, post_states, tb["rewards"][:-1])
+        kl = agent._kl_loss(post_params, prior_params)
+        img_b, img_s, img_params, ent = agent.imagine_ahead(post_states.detach(), beliefs.detach())
+        img_r = agent.reward_model(img_b, img_s)
+        img_v = agent.critic_target(img_b, img_s)
+        ret = dreamer_mod.lambda_return(img_r, img_v, bootstrap=img_v[-1], discount=agent.discount, lambda_=agent.disclam)
+        assert shims.checked == 3
+    # the stream must have been consumed in exactly synth.make_noise order
+    ns3 = synth.NoiseStream(seed)
+    for t in range(d.T):
+        ns3.exponential((d.B * d.cat_D, d.cat_C)); ns3.exponential((d.B * d.cat_D, d.cat_C))
+    for t in range(d.Hm):
+        ns3.normal((d.N, d.A)); ns3.normal((d.n_entropy, d.N, d.A)); ns3.exponential((d.N * d.cat_D, d.cat_C))
+    assert ns.calls == ns3.calls, "reference RNG call order differs from synth.make_noise (Categorical)"
+    assert len(prior_params) == 1 and len(post_params) == 1 and len(img_params) == 1
+    piece = dict(embeddings=emb, beliefs=beliefs, prior_states=prior_states, prior_logits=prior_params[0],
+                 posterior_states=post_states, posterior_logits=post_params[0], observation_loss=obs_loss,
+                 reward_loss=rew_loss, kl_loss=kl, imged_beliefs=img_b, imged_states=img_s,
+                 imged_prior_logits=img_params[0], action_entropy=ent, imged_reward=img_r, value_pred=img_v, returns=ret)
+    for k, v in piece.items():
+        store(out, f"piece.{k}", t2n(v), full)
+    agent.kl_balance = -1
+    out["piece.kl_loss_sum_branch"] = t2n(agent._kl_loss(post_params, prior_params))
+
+    agent = build_agent(dreamer_mod, d, P, **over)
+    agent.buffer.sample = lambda n, L: [tb["observations"], tb["actions"], tb["rewards"], tb["nonterminals"]]
+    norms = []
+    orig_clip = torch.nn.utils.clip_grad_norm_
+
+    def rec_clip(params, max_norm, norm_type=2):
+        r = orig_clip(params, max_norm, norm_type=norm_type)
+        norms.append(float(r))
+        return r
+
+    torch.nn.utils.clip_grad_norm_ = rec_clip
+    try:
+        for step in range(2):
+            ns = synth.NoiseStream(seed + step)
+            with Inject(ns), CategoricalShims(ns):
+                logs = agent.train_step()
+            if step == 0:
+                agent.update_critic()
+            for k, v in logs.items():
+                out[f"step{step}.log.{k}"] = np.array(v, dtype=np.float64)
+            out[f"step{step}.grad_norms"] = np.array(norms[-3:], dtype=np.float64)
+            for mod in ("transition_model", "observation_model", "reward_model", "encoder", "actor", "critic",
+                        "critic_target"):
+                for k, p in getattr(agent, mod).state_dict().items():
+                    store(out, f"step{step}.param.{mod}.{k}", t2n(p), full)
+                if mod == "critic_target":
+                    continue
+                for k, p in getattr(agent, mod).named_parameters():
+                    store(out, f"step{step}.grad.{mod}.{k}", t2n(p.grad), full)
+    finally:
+        torch.nn.utils.clip_grad_norm_ = orig_clip
+    out["fingerprint.params"] = np.array(sum(float(np.abs(v.astype(np.float64)).sum()) for sd in P.values()
+                                             for v in sd.values()))
+    out["fingerprint.batch"] = np.array(sum(float(np.abs(v.astype(np.float64)).sum()) for v in batch.values()))
+    nz = synth.make_noise(d, seed)
+    out["fingerprint.noise"] = np.array(sum(float(np.abs(v.astype(np.float64)).sum()) for v in nz.values()))
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+CATEGORICAL_RUNS = {        # name -> (Dims, seed, overrides); mirrored by tests/helpers.py CAT_CASES
+    "cat_tiny": (synth.CAT_TINY, 51, dict(free_nats=0.0)),                 # un-saturated clamp: KL gradients flow
+    "cat_tiny_klsum": (synth.CAT_TINY, 52, dict(kl_balance=-1, free_nats=0.01)),
+    "cat_32": (synth.CAT_32, 53, dict(free_nats=0.0)),                     # the reference's 32 x 32 latents, batch 18
+    "cat_32_v2": (synth.CAT_32, 54, dict()),                               # default free_nats=3 (clamp saturated)
+}
 
 
 def run_replay(memory_mod):
@@ -453,6 +607,8 @@ def main():
     run_config(dreamer_mod, "config3", synth.CONFIG3, full=False, seed=6)      # BASELINE configs[2], full size (~1 min)
     main_planner(dreamer_mod)
     run_act(dreamer_mod)
+    for name, (dd, sd_, ov) in CATEGORICAL_RUNS.items():
+        run_config_categorical(dreamer_mod, name, dd, sd_, **ov)
 
 
 if __name__ == "__main__":
@@ -461,6 +617,10 @@ if __name__ == "__main__":
         torch.set_num_threads(8)
         dm, mm = _import_reference()
         for what in sys.argv[sys.argv.index("--only") + 1:]:
+            if what == "categorical_scan":
+                for name, (dd, sd_, ov) in CATEGORICAL_RUNS.items():
+                    run_config_categorical(dm, name, dd, sd_, **ov)
+                continue
             {"config3": lambda: run_config(dm, "config3", synth.CONFIG3, full=False, seed=6),
              "act": lambda: run_act(dm)}[what]()
     elif "--planner-only" in sys.argv:       # regenerate only the planner / PlaNet vectors

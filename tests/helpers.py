@@ -21,6 +21,16 @@ CASES = {
 }
 
 
+# latent_distribution="Categorical" (configs[4] latents): name -> (Dims, seed, overrides, stored in full?)
+# golden = the reference's own Dreamer code under the two shims of oracle/gen_golden.py (CategoricalShims)
+CAT_CASES = {
+    "cat_tiny": (synth.CAT_TINY, 51, dict(free_nats=0.0), True),
+    "cat_tiny_klsum": (synth.CAT_TINY, 52, dict(kl_balance=-1, free_nats=0.01), True),
+    "cat_32": (synth.CAT_32, 53, dict(free_nats=0.0), False),
+    "cat_32_v2": (synth.CAT_32, 54, dict(), False),
+}
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False))
 

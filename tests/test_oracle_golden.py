@@ -181,3 +181,67 @@ def test_actor_forward_and_deterministic_action_against_reference():
     assert_close("std", std.numpy(), g["std"], 1e-6, 1e-5)
     assert_close("action", act.numpy(), g["action"], 1e-6, 1e-5)
     assert_close("entropy", ent.numpy(), g["entropy"], 2e-5, 2e-5)
+
+
+from tests.helpers import CAT_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(CAT_CASES))
+def test_categorical_scan_against_reference(name):
+    """latent_distribution="Categorical" end to end: the oracle against the reference's OWN Dreamer code run with the two
+    repairs it needs at HEAD (tests/golden/cat_*.npz, oracle/gen_golden.py CategoricalShims): forward pieces (sampled
+    one-hot states are exact), Categorical KL (both branches), two whole train steps (logs, clipped gradients, weights)."""
+    d, seed, hp, full = CAT_CASES[name]
+    g = load_golden(name)
+    P, batch, noise = synth.make_params(d, seed), synth.make_batch(d, seed), synth.make_noise(d, seed)
+    check_fingerprints(g, P, batch, noise)
+    torch.set_num_threads(8)
+    cat = (d.cat_D, d.cat_C)
+    od = O.OracleDreamer(P, dict(hp, planning_horizon=d.H, categorical=cat))
+    tb = {k: torch.as_tensor(v) for k, v in batch.items()}
+    tn = {k: torch.as_tensor(v) for k, v in noise.items()}
+    with torch.no_grad():
+        _, obs_loss, rew_loss, kl, inter = od.world_model_forward(tb, tn)
+        for k in ("embeddings", "beliefs", "prior_logits", "posterior_logits"):
+            compare_tensor(g, f"piece.{k}", inter[k].numpy(), full, atol=5e-6, rtol=1e-5)
+        for k in ("prior_states", "posterior_states"):        # one-hot samples: exact
+            compare_tensor(g, f"piece.{k}", inter[k].numpy(), full, atol=0.0, rtol=0.0)
+        assert_close("observation_loss", obs_loss.item(), g["piece.observation_loss"], 1e-6, 2e-6)
+        assert_close("reward_loss", rew_loss.item(), g["piece.reward_loss"], 1e-6, 2e-6)
+        assert_close("kl_loss", kl.numpy().reshape(-1), np.asarray(g["piece.kl_loss"]).reshape(-1), 1e-6, 5e-6)
+        assert_close("kl_sum_branch", O.kl_loss_categorical(inter["posterior_logits"], inter["prior_logits"], -1,
+                                                            od.hp["free_nats"]).numpy().reshape(-1),
+                     np.asarray(g["piece.kl_loss_sum_branch"]).reshape(-1), 1e-6, 5e-6)
+        ib, is_, (il,), ent = O.imagine_ahead(od.P, inter["posterior_states"], inter["beliefs"], d.H, tn["action"],
+                                              tn["entropy"], tn["img_prior"], cat)
+        compare_tensor(g, "piece.imged_beliefs", ib.numpy(), full, 5e-6, 1e-5)
+        compare_tensor(g, "piece.imged_states", is_.numpy(), full, 0.0, 0.0)
+        compare_tensor(g, "piece.imged_prior_logits", il.numpy(), full, 5e-6, 1e-5)
+        compare_tensor(g, "piece.action_entropy", ent.numpy(), full, 2e-5, 2e-5)
+        r = O.dense_on_features(ib, is_, od.P["reward_model"])
+        v = O.dense_on_features(ib, is_, od.P["critic_target"])
+        compare_tensor(g, "piece.returns", O.lambda_return(r, v, v[-1], od.hp["discount"], od.hp["disclam"]).numpy(), full,
+                       2e-5, 1e-5)
+    od = O.OracleDreamer(P, dict(hp, planning_horizon=d.H, categorical=cat))
+    for step in range(2):
+        logs = od.train_step(batch, synth.make_noise(d, seed + step))
+        if step == 0:
+            od.update_critic()
+        for k, v in logs.items():
+            assert_close(f"step{step}.{k}", v, g[f"step{step}.log.{k}"], 2e-6, 2e-5)
+        gn = od.last["grad_norms"]
+        assert_close(f"step{step}.grad_norms", [gn["model"], gn["actor"], gn["critic"]], g[f"step{step}.grad_norms"], 1e-6, 1e-4)
+        coef = {k: min(1.0, od.hp["grad_clip_norm"] / (gn[k] + 1e-6)) for k in gn}
+        groups = {"model": (O.MODEL_MODULES, od.last["model_grads"]), "actor": (("actor",), od.last["actor_grads"]),
+                  "critic": (("critic",), od.last["critic_grads"])}
+        for grp, (mods, grads) in groups.items():
+            i = 0
+            for mod in mods:
+                for k in od.P[mod]:
+                    gg = grads[i].numpy() * coef[grp]
+                    scale = float(np.abs(gg).max()) + 1e-12
+                    compare_tensor(g, f"step{step}.grad.{mod}.{k}", gg, full, atol=2e-5 * scale + 1e-9, rtol=2e-4)
+                    i += 1
+        for mod in list(O.MODEL_MODULES) + ["actor", "critic", "critic_target"]:
+            for k, p in od.P[mod].items():
+                compare_tensor(g, f"step{step}.param.{mod}.{k}", p.detach().numpy(), full, atol=2e-6, rtol=1e-6)
