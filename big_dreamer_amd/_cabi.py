@@ -99,6 +99,40 @@ class ImagineBwdArgs(C.Structure):
         ("dentropy", F32)] + _ptr_fields(["d_actor_pre", "d_actor_out"]))
 
 
+U8P = C.c_void_p
+
+
+class ObserveCatFwdArgs(C.Structure):
+    _fields_ = ([(n, I32) for n in ("T", "B", "Be", "D", "C", "A", "Hd")] + _ptr_fields(
+        ["w_embed_sT", "w_embed_a", "b_embed", "w_ir", "w_iz", "w_in", "w_hr", "w_hz", "w_hn", "b_ih", "b_hh",
+         "w_q1h", "b_q1", "w_q2", "b_q2", "init_belief", "init_state", "actions", "nonterm", "pre_emb", "q_post",
+         "feat", "post_logits", "sidx", "sv_s", "sv_x", "sv_gates", "sv_q"]))
+
+
+class ObserveCatBwdArgs(C.Structure):
+    _fields_ = ([(n, I32) for n in ("T", "B", "Be", "D", "C", "A", "Hd")] + _ptr_fields(
+        ["wt_embed_s", "wt_ir", "wt_iz", "wt_in", "wt_hr", "wt_hz", "wt_hn", "wt_q1h", "wt_q2", "init_belief", "nonterm",
+         "feat", "post_logits", "sv_x", "sv_gates", "sv_q", "dfeat", "dpost_logits", "d_embed_pre", "d_gi", "d_gh",
+         "d_q1_pre", "d_q2_out"]))
+
+
+class ImagineCatFwdArgs(C.Structure):
+    _fields_ = ([(n, I32) for n in ("N", "Hm", "Be", "D", "C", "A", "Hd", "n_samples")] + _ptr_fields(
+        ["w_embed_sT", "w_embed_a", "b_embed", "w_ir", "w_iz", "w_in", "w_hr", "w_hz", "w_hn", "b_ih", "b_hh", "w_p1",
+         "b_p1", "w_p2", "b_p2", "w_a0h", "w_a0sT"]) + [("w_a", P * 3), ("b_a", P * 4)] + _ptr_fields(
+        ["w_a4m", "w_a4s", "b_a4", "start_feat", "start_sidx", "eps_action", "eps_entropy", "q_prior"]) + [
+        ("act_raw_init_std", F32), ("act_min_std", F32), ("act_mean_scale", F32)] + _ptr_fields(
+        ["feat", "sidx", "prior_logits", "entropy", "action", "sv_actor", "sv_act_stats", "sv_x", "sv_gates", "sv_p"]))
+
+
+class ImagineCatBwdArgs(C.Structure):
+    _fields_ = ([(n, I32) for n in ("N", "Hm", "Be", "D", "C", "A", "Hd")] + _ptr_fields(
+        ["wt_embed_s", "wt_embed_a", "wt_ir", "wt_iz", "wt_in", "wt_hr", "wt_hz", "wt_hn", "wt_p1", "wt_p2"]) + [
+        ("wt_a", P * 3)] + _ptr_fields(
+        ["wt_a4m", "wt_a4s", "start_feat", "feat", "prior_logits", "action", "eps_action", "sv_actor", "sv_act_stats",
+         "sv_x", "sv_gates", "sv_p", "dfeat"]) + [("dentropy", F32)] + _ptr_fields(["d_actor_pre", "d_actor_out"]))
+
+
 class PlanArgs(C.Structure):
     _fields_ = ([(n, I32) for n in ("rows", "H", "cand", "Be", "S", "A", "Hd")] + _ptr_fields(
         ["w_embed_s", "w_embed_a", "b_embed", "w_ir", "w_iz", "w_in", "w_hr", "w_hz", "w_hn", "b_ih", "b_hh", "w_p1",
@@ -139,6 +173,10 @@ _SIGS = {
     "bd_observe_cluster_set_spin_limit": (I32, [C.c_uint]),
     "bd_gauss_head_forward": (I32, [P, P, I32, I32, F32, P, P, P, P]),
     "bd_gauss_head_backward": (I32, [P, P, P, P, P, I32, I32, P, P]),
+    "bd_observe_cat_forward": (I32, [C.POINTER(ObserveCatFwdArgs), P]),
+    "bd_observe_cat_backward": (I32, [C.POINTER(ObserveCatBwdArgs), P]),
+    "bd_imagine_cat_forward": (I32, [C.POINTER(ImagineCatFwdArgs), P]),
+    "bd_imagine_cat_backward": (I32, [C.POINTER(ImagineCatBwdArgs), P]),
     "bd_imagine_forward": (I32, [C.POINTER(ImagineFwdArgs), P]),
     "bd_imagine_backward": (I32, [C.POINTER(ImagineBwdArgs), P]),
     "bd_lambda_return_forward": (I32, [P, P, I32, I32, F32, F32, P, P]),

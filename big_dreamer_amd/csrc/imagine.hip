@@ -11,6 +11,7 @@
 //   x = ELU(W_e [s; a] + b_e);  h' = GRUCell(x, h);  p = ELU(W_p1 h' + b);  s' = mean_p + std_p * eps_p
 #include "bd_device.h"
 #include "bd_host.h"
+#include "bd_scan.h"
 
 namespace bd {
 
@@ -37,98 +38,6 @@ struct ImgDims {
         : Kb_h(cdiv(Be, 16)), Kb_s(cdiv(S, 16)), Kb_a(cdiv(A, 16)), Kb_hd(cdiv(Hd, 16)) {}
 };
 
-// One sample of the entropy estimate: log-density of y = tanh(mean + std*e) under the tanh-Normal, and its
-// derivatives w.r.t. mean and std following the reference's autograd graph (rsample -> tanh -> clamp ->
-// atanh -> Normal.log_prob - log|det J|).  Terms that depend only on (row, action dim) -- log std, 1/std^2,
-// 1/std -- are hoisted by the caller; exp(-2x) is shared by softplus(-2x) and sigmoid(-2x).
-struct EntConst {
-    float mean, sd, inv_var, inv_sd, base0;     // base0 = -log(sd) - log(sqrt(2 pi)) - 2 ln 2
-};
-__device__ __forceinline__ EntConst entropy_const(float mean, float sd) {
-    constexpr float kLogSqrt2Pi = 0.91893853320467274f, kLn2 = 0.69314718055994531f;
-    return EntConst{mean, sd, 1.f / (sd * sd), 1.f / sd, -logf(sd) - kLogSqrt2Pi - 2.f * kLn2};
-}
-__device__ __forceinline__ void entropy_sample(const EntConst& c, float e, float& lp, float& dm, float& ds) {
-    constexpr float kClamp = 0.99999994f;                // float32(0.99999997), src/models.py:663
-    const float u = c.mean + c.sd * e;
-    const float y = tanhf(u);
-    const float yc = fminf(fmaxf(y, -kClamp), kClamp);
-    const float a = 1.f + yc, b = 1.f - yc;
-    const float xh = 0.5f * logf(a / b);                 // atanh (src/models.py:627)
-    const float diff = xh - c.mean;
-    const float t = -2.f * xh;
-    const float ex = expf(t);                            // shared: softplus(t) = log1p(ex), sigmoid(t) = ex / (1 + ex)
-    const float sp = t > 20.f ? t : log1pf(ex);          // F.softplus threshold
-    const float sg = t > 20.f ? 1.f : ex / (1.f + ex);
-    // log p = -(xh-mean)^2/(2 sd^2) - log sd - log sqrt(2pi) - 2 (ln 2 - xh - softplus(-2 xh))     (src/models.py:673)
-    lp = c.base0 - 0.5f * diff * diff * c.inv_var + 2.f * (xh + sp);
-    const float gx = -diff * c.inv_var + 2.f - 4.f * sg;                    // d lp / d xh
-    const bool pass = (y >= -kClamp) && (y <= kClamp);                      // clamp backward mask
-    const float J = pass ? (1.f - y * y) / (a * b) : 0.f;                   // d xh / d u = (1 - y^2) / ((1+yc)(1-yc))
-    dm = diff * c.inv_var + gx * J;
-    ds = diff * diff * c.inv_var * c.inv_sd - c.inv_sd + gx * J * e;
-}
-
-// hidden layer epilogue: ELU -> LDS fragment (+ optional save for the backward)
-struct HiddenEpi {
-    float* dst;
-    float* save;
-    size_t tn;
-    int width, rows, row0, lane;
-    __device__ __forceinline__ void operator()(int nb, floatx4 acc) const {
-        const int col = nb * 16 + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int grow = row0 + 4 * (lane >> 4) + r;
-            const bool ok = grow < rows && col < width;
-            const float v = ok ? elu(acc[r]) : 0.f;
-            dst[acc_frag_off(nb, lane, r)] = v;
-            if (ok && save) save[(tn + grow) * width + col] = v;
-        }
-    }
-};
-
-// "gradient w.r.t. a hidden ELU output" epilogue: multiply by ELU' (from the saved output), keep in LDS for the
-// next contraction (dst may be null) and store for bd_wgrad (out may be null).
-struct DpreEpi {
-    float* dst;
-    float* out;
-    size_t tn;
-    int width, rows, row0, lane;
-    __device__ __forceinline__ void operator()(int, int nb, floatx4 acc, const Pre4& p) const {
-        const int col = nb * 16 + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int grow = row0 + 4 * (lane >> 4) + r;
-            float v = 0.f;
-            if (grow < rows && col < width) {
-                v = acc[r] * elu_grad_from_out(p.v[r]);
-                if (out) out[(tn + grow) * width + col] = v;
-            }
-            if (dst) dst[acc_frag_off(nb, lane, r)] = v;
-        }
-    }
-};
-// the saved ELU outputs that DpreEpi needs, fetched before the contraction
-struct DprePre {
-    const float* saved;
-    size_t tn;
-    int width, rows, row0, lane;
-    __device__ __forceinline__ Pre4 operator()(int, int nb) const {
-        Pre4 p;
-        const int col = nb * 16 + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int grow = row0 + 4 * (lane >> 4) + r;
-            p.v[r] = (grow < rows && col < width) ? saved[(tn + grow) * width + col] : 1.f;
-        }
-        return p;
-    }
-};
-
-struct PreAct {          // operands of the action-sample backward per accumulator row
-    float act[4], th[4], sg[4], dm[4], ds[4], eps[4];
-};
 
 __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

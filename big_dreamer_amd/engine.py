@@ -426,22 +426,32 @@ class DreamerEngine:
 
         tm = lambda n: self.W("transition_model", n)
         We = tm("fc_embed_state_action.0.weight")
-        add("model", "embed_s", We[:, :S], tr=True)
+        cat = d.categorical
+        # Categorical latents: the state columns of a first layer are GATHERED (csrc/scan_cat.hip), from plain
+        # transposed copies [S x out] refreshed with the packs (self._plain); only their transposes are packed (dgrad)
+        self._plain: Dict[str, Tuple[torch.Tensor, torch.Tensor, str]] = {}
+        add("model", "embed_s", We[:, :S], fwd=not cat, tr=True)
         add("model", "embed_a", We[:, S:], tr=True)
+        if cat:
+            self._plain["embed_sT"] = (torch.zeros(S, Be, dtype=torch.float32, device=self.dev), We[:, :S], "model")
         for gi, gname in enumerate("rzn"):
             add("model", f"i{gname}", tm("rnn.weight_ih")[gi * Be:(gi + 1) * Be], tr=True)
             add("model", f"h{gname}", tm("rnn.weight_hh")[gi * Be:(gi + 1) * Be], tr=True)
         add("model", "p1", tm("belief_prior.model.0.weight"), tr=True)
         Wp2 = tm("belief_prior.model.2.weight")
         add("model", "p2", Wp2, tr=True)
-        add("model", "p2m", Wp2[:S], tr=True)
-        add("model", "p2s", Wp2[S:], tr=True)
+        if not cat:
+            add("model", "p2m", Wp2[:S], tr=True)
+            add("model", "p2s", Wp2[S:], tr=True)
         Wq1 = tm("belief_posterior.model.0.weight")
         add("model", "q1h", Wq1[:, :Be], tr=True)
         add("model", "q1e", Wq1[:, Be:], tr=True)
         Wq2 = tm("belief_posterior.model.2.weight")
-        add("model", "q2m", Wq2[:S], tr=True)
-        add("model", "q2s", Wq2[S:], tr=True)
+        if cat:
+            add("model", "q2", Wq2, tr=True)
+        else:
+            add("model", "q2m", Wq2[:S], tr=True)
+            add("model", "q2s", Wq2[S:], tr=True)
         for l in range(DENSE_LAYERS + 1):
             if not self.pixel:
                 add("model", f"enc{l}", self.W("encoder", f"model.{2 * l}.weight"), tr=(l > 0))
@@ -451,7 +461,10 @@ class DreamerEngine:
             add("critic_target", f"tgt{l}", self.W("critic_target", f"model.{2 * l}.weight"), tr=True)
         Wa0 = self.W("actor", "model.0.weight")
         add("actor", "a0h", Wa0[:, :Be])
-        add("actor", "a0s", Wa0[:, Be:])
+        if cat:
+            self._plain["a0sT"] = (torch.zeros(S, Hd, dtype=torch.float32, device=self.dev), Wa0[:, Be:], "actor")
+        else:
+            add("actor", "a0s", Wa0[:, Be:])
         for l in range(1, DENSE_LAYERS):
             add("actor", f"a{l}", self.W("actor", f"model.{2 * l}.weight"), tr=True)
         Wa4 = self.W("actor", f"model.{2 * DENSE_LAYERS}.weight")
@@ -477,6 +490,9 @@ class DreamerEngine:
     def pack(self, group: str) -> None:
         raw, n, _ = self._pack_tables[group]
         cabi.check(lib.bd_pack_weights(raw.data_ptr(), n, cabi.stream()))
+        for dst, src, grp in self._plain.values():          # Categorical latents: plain transposes for the gathers
+            if grp == group:
+                dst.copy_(src.t())
         if group == "model" and self.conv is not None:
             self.conv.pack()
 
@@ -671,6 +687,9 @@ class DreamerEngine:
         the posterior (embeddings given) or, with prior_only=True (embeddings=None, src/models.py:241,296-297), the
         prior -- the same kernel run with the prior head's weights and a zero embedding projection."""
         d, pk = self.d, self.pk
+        if d.categorical:
+            return self._observe_cat(actions, nonterm, pre_emb, eps_post, init_belief, init_state, T, B, save, tag,
+                                     prior_only, feat_tag)
         tm = lambda n: self.W("transition_model", n)
         M = T * B
         a = cabi.ObserveFwdArgs()
@@ -703,6 +722,86 @@ class DreamerEngine:
                 cabi.check(lib.bd_observe_forward(C.byref(a), cabi.stream()))
         return feat, qm, qs
 
+    def _observe_cat(self, actions, nonterm, pre_emb, q_post, init_belief, init_state, T, B, save, tag, prior_only, feat_tag):
+        """Categorical latents: TransitionModel.forward recurrence on bd_observe_cat_forward.  Returns feat
+        [T*B x (Be+S)] ([h; one-hot s]), the logits of the fed-back state twice (the Gaussian signature's mean / std
+        slots), and leaves the class indices in buf(tag + feat_tag + "sidx")."""
+        d, pk = self.d, self.pk
+        tm = lambda n: self.W("transition_model", n)
+        M = T * B
+        a = cabi.ObserveCatFwdArgs()
+        a.T, a.B, a.Be, a.D, a.C, a.A, a.Hd = T, B, d.Be, d.cat_D, d.cat_C, d.A, d.Hd
+        a.w_embed_sT, a.w_embed_a = ptr(self._plain["embed_sT"][0]), ptr(pk["embed_a"])
+        a.b_embed = ptr(tm("fc_embed_state_action.0.bias"))
+        a.w_ir, a.w_iz, a.w_in = ptr(pk["ir"]), ptr(pk["iz"]), ptr(pk["in"])
+        a.w_hr, a.w_hz, a.w_hn = ptr(pk["hr"]), ptr(pk["hz"]), ptr(pk["hn"])
+        a.b_ih, a.b_hh = ptr(tm("rnn.bias_ih")), ptr(tm("rnn.bias_hh"))
+        if prior_only:
+            a.w_q1h, a.b_q1 = ptr(pk["p1"]), ptr(tm("belief_prior.model.0.bias"))
+            a.w_q2, a.b_q2 = ptr(pk["p2"]), ptr(tm("belief_prior.model.2.bias"))
+            pre_emb = self.buf(tag + "zero_pre_emb", M, d.Hd)
+        else:
+            a.w_q1h, a.b_q1 = ptr(pk["q1h"]), ptr(tm("belief_posterior.model.0.bias"))
+            a.w_q2, a.b_q2 = ptr(pk["q2"]), ptr(tm("belief_posterior.model.2.bias"))
+        a.init_belief, a.init_state, a.actions = ptr(init_belief), ptr(init_state), ptr(actions)
+        a.nonterm, a.pre_emb, a.q_post = ptr(nonterm), ptr(pre_emb), ptr(q_post)
+        feat = self.buf(tag + feat_tag + "feat", M, d.Be + d.S)
+        logits = self.buf(tag + "post_logits", M, d.S)
+        sidx = self._buf_u8(tag + feat_tag + "sidx", M, d.cat_D)
+        a.feat, a.post_logits, a.sidx = ptr(feat), ptr(logits), ptr(sidx)
+        if save:
+            a.sv_s, a.sv_x = ptr(self.buf("sv_s", M, d.S)), ptr(self.buf("sv_x", M, d.Be))
+            a.sv_gates, a.sv_q = ptr(self.buf("sv_gates", M, 4 * d.Be)), ptr(self.buf("sv_q", M, d.Hd))
+        with self.span("observe_fwd"):
+            cabi.check(lib.bd_observe_cat_forward(C.byref(a), cabi.stream()))
+        return feat, logits, logits
+
+    def _buf_u8(self, name: str, *shape) -> torch.Tensor:
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.zeros(*shape, dtype=torch.uint8, device=self.dev)
+            self._buf[name] = t
+        return t
+
+    def _imagine_cat(self, start_feat, start_sidx, N: int, Hm: int, noise, save: bool, tag: str, feat_tag: str):
+        d, pk = self.d, self.pk
+        tm = lambda n: self.W("transition_model", n)
+        ac = lambda n: self.W("actor", n)
+        Mi = Hm * N
+        a = cabi.ImagineCatFwdArgs()
+        a.N, a.Hm, a.Be, a.D, a.C, a.A, a.Hd, a.n_samples = N, Hm, d.Be, d.cat_D, d.cat_C, d.A, d.Hd, d.n_entropy
+        a.w_embed_sT, a.w_embed_a = ptr(self._plain["embed_sT"][0]), ptr(pk["embed_a"])
+        a.b_embed = ptr(tm("fc_embed_state_action.0.bias"))
+        a.w_ir, a.w_iz, a.w_in = ptr(pk["ir"]), ptr(pk["iz"]), ptr(pk["in"])
+        a.w_hr, a.w_hz, a.w_hn = ptr(pk["hr"]), ptr(pk["hz"]), ptr(pk["hn"])
+        a.b_ih, a.b_hh = ptr(tm("rnn.bias_ih")), ptr(tm("rnn.bias_hh"))
+        a.w_p1, a.b_p1 = ptr(pk["p1"]), ptr(tm("belief_prior.model.0.bias"))
+        a.w_p2, a.b_p2 = ptr(pk["p2"]), ptr(tm("belief_prior.model.2.bias"))
+        a.w_a0h, a.w_a0sT = ptr(pk["a0h"]), ptr(self._plain["a0sT"][0])
+        for l in range(1, DENSE_LAYERS):
+            a.w_a[l - 1] = ptr(pk[f"a{l}"])
+        for l in range(DENSE_LAYERS):
+            a.b_a[l] = ptr(ac(f"model.{2 * l}.bias"))
+        a.w_a4m, a.w_a4s, a.b_a4 = ptr(pk["a4m"]), ptr(pk["a4s"]), ptr(ac(f"model.{2 * DENSE_LAYERS}.bias"))
+        a.start_feat, a.start_sidx = ptr(start_feat), ptr(start_sidx)
+        a.eps_action, a.eps_entropy, a.q_prior = ptr(noise["action"]), ptr(noise["entropy"]), ptr(noise["img_prior"])
+        a.act_raw_init_std, a.act_min_std, a.act_mean_scale = ACT_RAW_INIT_STD, ACT_MIN_STD, ACT_MEAN_SCALE
+        ifeat = self.buf(tag + feat_tag + "ifeat", Mi, d.Be + d.S)
+        a.feat = ptr(ifeat)
+        a.sidx = ptr(self._buf_u8(tag + "isidx", Mi, d.cat_D))
+        a.prior_logits = ptr(self.buf(tag + "iprior_logits", Mi, d.S))
+        ent, act = self.buf(tag + "entropy", Mi), self.buf(tag + "action", Mi, d.A)
+        a.entropy, a.action = ptr(ent), ptr(act)
+        if save:
+            a.sv_actor = ptr(self.buf("sv_actor", DENSE_LAYERS, Mi, d.Hd))
+            a.sv_act_stats = ptr(self.buf("sv_act_stats", Mi, 4 * d.A))
+            a.sv_x, a.sv_gates = ptr(self.buf("isv_x", Mi, d.Be)), ptr(self.buf("isv_gates", Mi, 4 * d.Be))
+            a.sv_p = ptr(self.buf("isv_p", Mi, d.Hd))
+        with self.span("imagine_fwd"):
+            cabi.check(lib.bd_imagine_cat_forward(C.byref(a), cabi.stream()))
+        self._img_split_rows = 0
+        return ifeat, ent, act
+
     def _cluster_ok(self, B: int) -> bool:
         """Cluster scan only while its tiles*C one-per-CU members leave half the chip to the kernels the other pipeline
         streams run beside it (members claim a whole CU's LDS and advance in lock step: on a crowded chip they would
@@ -727,13 +826,21 @@ class DreamerEngine:
             cabi.check(lib.bd_observe_cluster_status(ptr(self._obs_ws), B, cabi.stream()))
 
     def prior_head(self, feat, M: int, eps, tag: str = ""):
-        """belief_prior on all beliefs at once (src/models.py:256): returns state, mean, std [M x S]."""
+        """belief_prior on all beliefs at once (src/models.py:256): returns state, mean, std [M x S] -- Categorical
+        latents: (state or None when eps is None, logits, logits)."""
         d = self.d
         tm = lambda n: self.W("transition_model", n)
         layers = [("p1", tm("belief_prior.model.0.bias"), d.Hd, d.Be, cabi.ACT_ELU),
-                  ("p2", tm("belief_prior.model.2.bias"), 2 * d.S, d.Hd, cabi.ACT_NONE)]
-        hid, out = self.buf(tag + "p_hid", M, d.Hd), self.buf(tag + "p_out", M, 2 * d.S)
-        self.mlp_forward(M, feat, d.Be + d.S, d.Be, layers, [hid, None], out, 2 * d.S)
+                  ("p2", tm("belief_prior.model.2.bias"), d.head_out, d.Hd, cabi.ACT_NONE)]
+        hid, out = self.buf(tag + "p_hid", M, d.Hd), self.buf(tag + "p_out", M, d.head_out)
+        self.mlp_forward(M, feat, d.Be + d.S, d.Be, layers, [hid, None], out, d.head_out)
+        if d.categorical:
+            pst = None
+            if eps is not None:     # the sampled prior state is not on the training path (src/models.py:256 draws it anyway)
+                pst, probs = self.buf(tag + "prior_state", M, d.S), self.buf(tag + "prior_probs", M, d.S)
+                cabi.check(lib.bd_categorical_head_forward(ptr(out), ptr(eps), M, d.cat_D, d.cat_C, ptr(pst), ptr(probs),
+                                                           cabi.stream()))
+            return pst, out, out
         pm, ps, pst = (self.buf(tag + "prior_mean", M, d.S), self.buf(tag + "prior_std", M, d.S),
                        self.buf(tag + "prior_state", M, d.S))
         cabi.check(lib.bd_gauss_head_forward(ptr(out), ptr(eps), M, d.S, self.hp["min_std_dev"], ptr(pm), ptr(ps),
@@ -755,8 +862,12 @@ class DreamerEngine:
         return out, acts, layers
 
     def imagine(self, start_feat, N: int, Hm: int, noise, save: bool = True, tag: str = "", feat_tag: str = "",
-                split: bool = False):
+                split: bool = False, start_sidx: Optional[torch.Tensor] = None):
         d, pk = self.d, self.pk
+        if d.categorical:
+            if start_sidx is None:      # API callers hand dense one-hot states
+                start_sidx = start_feat[:, d.Be:].reshape(N, d.cat_D, d.cat_C).argmax(-1).to(torch.uint8).contiguous()
+            return self._imagine_cat(start_feat, start_sidx, N, Hm, noise, save, tag, feat_tag)
         tm = lambda n: self.W("transition_model", n)
         ac = lambda n: self.W("actor", n)
         Mi = Hm * N
@@ -887,6 +998,10 @@ class DreamerEngine:
             shapes.update(obs_prior=(T, B, d.S), obs_post=(T, B, d.S))
         if part in ("all", "bh"):
             shapes.update(action=(Hm, N, d.A), entropy=(Hm, d.n_entropy, N, d.A), img_prior=(Hm, N, d.S))
+        if d.categorical:       # the state draws are the sampler's Exp(1) variates, one per class (torch.multinomial)
+            shapes.pop("obs_prior", None)       # the prior sample is not on the training path
+            return {k: (self.buf("noise_" + k, *s).exponential_() if k in ("obs_post", "img_prior")
+                        else self.buf("noise_" + k, *s).normal_()) for k, s in shapes.items()}
         return {k: self.buf("noise_" + k, *s).normal_() for k, s in shapes.items()}
 
     def _optimizer_step_or_defer(self, span: str, group: str, slot: int, lr: float, red_ws: torch.Tensor) -> None:
@@ -997,7 +1112,8 @@ class DreamerEngine:
         T, B = obs.shape[0] - 1, obs.shape[1]
         self._timer_tick += 1
         self._dynamics_phase(batch, noise if noise is not None else self.make_noise(B, "wm"), "")
-        self._counts = dict(N=T * B, Mi=1, S=self.d.S, sum_form=int(self.hp["kl_balance"] == -1))
+        self._counts = dict(N=T * B, Mi=1, S=(self.d.cat_D if self.d.categorical else self.d.S),
+                            sum_form=int(self.hp["kl_balance"] == -1))
         if not sync_logs:
             return {}
         return {k: v for k, v in self.logs().items() if k in ("observation_loss", "reward_loss", "kl_loss", "model_loss",
@@ -1023,8 +1139,9 @@ class DreamerEngine:
         init_state = self.buf("init_state", B, d.S).zero_()
         feat, qm, qs = self.observe(actions[:-1], nonterm[:-1], pre_emb, noise["obs_post"], init_belief, init_state, T, B,
                                     feat_tag=feat_tag)
+        cat = d.categorical
         with self.span("wm_heads_fwd"):
-            _, pm, ps = self.prior_head(feat, N, noise["obs_prior"])
+            _, pm, ps = self.prior_head(feat, N, None if cat else noise["obs_prior"])
             if self.conv is not None:
                 om_out, om_acts, om_layers = self.conv.decode(feat).view(N, d.O), None, None
                 obs_t = self.conv.acts_enc[0].view(N, d.O)      # the same images in the NHWC order of the prediction
@@ -1039,16 +1156,28 @@ class DreamerEngine:
         cabi.check(lib.bd_normal_nll(ptr(om_out), d.O, ptr(obs_t), d.O, N, d.O, inv_rows, ptr(d_om), d.O, sc, SLOT_OBS, ws, st))
         cabi.check(lib.bd_normal_nll(ptr(rw_out), 1, ptr(rewards[:-1]), 1, N, 1, inv_rows, ptr(d_rw), 1, sc, SLOT_REW, ws, st))
         sum_form = int(hp["kl_balance"] == -1)
-        cabi.check(lib.bd_kl_forward(ptr(qm), ptr(qs), ptr(pm), ptr(ps), N, d.S, hp["free_nats"], sum_form, sc, SLOT_KL, ws, st))
+        kl_n = d.cat_D if cat else d.S                      # KL terms per row: one per factor / per state dimension
+        if cat:     # Categorical branch of _kl_loss (src/dreamer.py:102-106,119-144): qm / pm are the logits
+            cabi.check(lib.bd_kl_categorical_forward(ptr(qm), ptr(pm), N, d.cat_D, d.cat_C, hp["free_nats"], sum_form, sc,
+                                                     SLOT_KL, ws, st))
+        else:
+            cabi.check(lib.bd_kl_forward(ptr(qm), ptr(qs), ptr(pm), ptr(ps), N, d.S, hp["free_nats"], sum_form, sc, SLOT_KL,
+                                         ws, st))
         if W > 1 and not sum_form:                          # the free-nats clamp acts on the GLOBAL mean
             self._kl_local = self.scalars[SLOT_KL:SLOT_KL + 1].clone()
             self._allreduce(self.scalars[SLOT_KL:SLOT_KL + 1], "model")
-        dqm, dqs = self.buf("dqm", N, d.S), self.buf("dqs", N, d.S)
-        dpm, dps = self.buf("dpm", N, d.S), self.buf("dps", N, d.S)
-        kl_inv = 1.0 / (N * d.S * W) if not sum_form else 1.0 / (N * W)
-        cabi.check(lib.bd_kl_backward(ptr(qm), ptr(qs), ptr(pm), ptr(ps), N, d.S, hp["free_nats"], hp["kl_balance"],
-                                      hp["kl_loss_weight"] * (1.0 / W if sum_form else 1.0), kl_inv, sc, SLOT_KL,
-                                      ptr(dqm), ptr(dqs), ptr(dpm), ptr(dps), st))
+        kl_inv = 1.0 / (N * kl_n * W) if not sum_form else 1.0 / (N * W)
+        kl_w = hp["kl_loss_weight"] * (1.0 / W if sum_form else 1.0)
+        if cat:
+            dqm, dpm = self.buf("dql", N, d.S), self.buf("dpl", N, d.S)
+            dqs = dps = None
+            cabi.check(lib.bd_kl_categorical_backward(ptr(qm), ptr(pm), N, d.cat_D, d.cat_C, hp["free_nats"], hp["kl_balance"],
+                                                      kl_w, kl_inv, sc, SLOT_KL, ptr(dqm), ptr(dpm), st))
+        else:
+            dqm, dqs = self.buf("dqm", N, d.S), self.buf("dqs", N, d.S)
+            dpm, dps = self.buf("dpm", N, d.S), self.buf("dps", N, d.S)
+            cabi.check(lib.bd_kl_backward(ptr(qm), ptr(qs), ptr(pm), ptr(ps), N, d.S, hp["free_nats"], hp["kl_balance"],
+                                          kl_w, kl_inv, sc, SLOT_KL, ptr(dqm), ptr(dqs), ptr(dpm), ptr(dps), st))
 
         # ---- backward of the world model ----
         dfeat = self.buf("dfeat", N, F)
@@ -1079,15 +1208,47 @@ class DreamerEngine:
                               accumulate=True)
         # prior head: KL gradient on (mean, std) -> belief part of dfeat
         p_out, p_hid = self._buf["p_out"], self._buf["p_hid"]
-        d_p_out, d_p_hid = self.buf("d_p_out", N, 2 * d.S), self.buf("d_p_hid", N, d.Hd)
-        cabi.check(lib.bd_gauss_head_backward(ptr(p_out), None, None, ptr(dpm), ptr(dps), N, d.S, ptr(d_p_out), st))
+        HO = d.head_out
+        d_p_hid = self.buf("d_p_hid", N, d.Hd)
+        if cat:
+            d_p_out = dpm                                   # the KL gradient w.r.t. the prior logits IS d(head output)
+        else:
+            d_p_out = self.buf("d_p_out", N, HO)
+            cabi.check(lib.bd_gauss_head_backward(ptr(p_out), None, None, ptr(dpm), ptr(dps), N, d.S, ptr(d_p_out), st))
         tm = lambda n: self.W("transition_model", n)
-        p_layers = [("p1", None, d.Hd, d.Be, cabi.ACT_ELU), ("p2", None, 2 * d.S, d.Hd, cabi.ACT_NONE)]
-        self.mlp_backward(N, d_p_out, 2 * d.S, p_layers, [p_hid, None], [d_p_hid, None], din0=dfeat, ld0=F, w0=d.Be,
+        p_layers = [("p1", None, d.Hd, d.Be, cabi.ACT_ELU), ("p2", None, HO, d.Hd, cabi.ACT_NONE)]
+        self.mlp_backward(N, d_p_out, HO, p_layers, [p_hid, None], [d_p_hid, None], din0=dfeat, ld0=F, w0=d.Be,
                           accumulate=True)
         # recurrence
-        b = cabi.ObserveBwdArgs()
+        d_e, d_gi, d_gh = self.buf("d_embed_pre", N, d.Be), self.buf("d_gi", N, 3 * d.Be), self.buf("d_gh", N, 3 * d.Be)
+        d_q1, d_q2 = self.buf("d_q1_pre", N, d.Hd), self.buf("d_q2_out", N, HO)
         pk = self.pk
+        if cat:
+            b = cabi.ObserveCatBwdArgs()
+            b.T, b.B, b.Be, b.D, b.C, b.A, b.Hd = T, B, d.Be, d.cat_D, d.cat_C, d.A, d.Hd
+            b.wt_embed_s = ptr(pk["embed_s.T"])
+            b.wt_ir, b.wt_iz, b.wt_in = ptr(pk["ir.T"]), ptr(pk["iz.T"]), ptr(pk["in.T"])
+            b.wt_hr, b.wt_hz, b.wt_hn = ptr(pk["hr.T"]), ptr(pk["hz.T"]), ptr(pk["hn.T"])
+            b.wt_q1h, b.wt_q2 = ptr(pk["q1h.T"]), ptr(pk["q2.T"])
+            b.init_belief, b.nonterm = ptr(init_belief), ptr(nonterm[:-1])
+            b.feat, b.post_logits = ptr(feat), ptr(qm)
+            b.sv_x, b.sv_gates, b.sv_q = ptr(self._buf["sv_x"]), ptr(self._buf["sv_gates"]), ptr(self._buf["sv_q"])
+            b.dfeat, b.dpost_logits = ptr(dfeat), ptr(dqm)
+            b.d_embed_pre, b.d_gi, b.d_gh, b.d_q1_pre, b.d_q2_out = ptr(d_e), ptr(d_gi), ptr(d_gh), ptr(d_q1), ptr(d_q2)
+            with self.span("observe_bwd"):
+                cabi.check(lib.bd_observe_cat_backward(C.byref(b), st))
+        else:
+            self._observe_backward_gaussian(T, B, init_belief, nonterm, noise, feat, qs, dfeat, dqm, dqs, d_e, d_gi, d_gh,
+                                            d_q1, d_q2, st)
+        self._dynamics_tail(batch, emb, obs_t, feat, init_belief, actions, d_e, d_gi, d_gh, d_q1, d_q2, d_p_hid, d_p_out,
+                            p_hid, rw_dpre, rw_acts, om_dpre if (not self.pixel) else None,
+                            om_acts if (not self.pixel) else None, N, B, F)
+        return feat
+
+    def _observe_backward_gaussian(self, T, B, init_belief, nonterm, noise, feat, qs, dfeat, dqm, dqs, d_e, d_gi, d_gh, d_q1,
+                                   d_q2, st) -> None:
+        d, hp, pk = self.d, self.hp, self.pk
+        b = cabi.ObserveBwdArgs()
         b.T, b.B, b.Be, b.S, b.A, b.Hd = T, B, d.Be, d.S, d.A, d.Hd
         b.wt_embed_s = ptr(pk["embed_s.T"])
         b.wt_ir, b.wt_iz, b.wt_in = ptr(pk["ir.T"]), ptr(pk["iz.T"]), ptr(pk["in.T"])
@@ -1098,8 +1259,6 @@ class DreamerEngine:
         b.sv_x, b.sv_gates, b.sv_q = ptr(self._buf["sv_x"]), ptr(self._buf["sv_gates"]), ptr(self._buf["sv_q"])
         b.dfeat, b.dpost_mean, b.dpost_std = ptr(dfeat), ptr(dqm), ptr(dqs)
         b.min_std = hp["min_std_dev"]
-        d_e, d_gi, d_gh = self.buf("d_embed_pre", N, d.Be), self.buf("d_gi", N, 3 * d.Be), self.buf("d_gh", N, 3 * d.Be)
-        d_q1, d_q2 = self.buf("d_q1_pre", N, d.Hd), self.buf("d_q2_out", N, 2 * d.S)
         b.d_embed_pre, b.d_gi, b.d_gh, b.d_q1_pre, b.d_q2_out = ptr(d_e), ptr(d_gi), ptr(d_gh), ptr(d_q1), ptr(d_q2)
         with self.span("observe_bwd"):
             if self._cluster_ok(B):
@@ -1107,6 +1266,12 @@ class DreamerEngine:
                 cabi.check(lib.bd_observe_backward_cluster(C.byref(b), ptr(ws_c), ws_c.numel(), st))
             else:
                 cabi.check(lib.bd_observe_backward(C.byref(b), st))
+
+    def _dynamics_tail(self, batch, emb, obs_t, feat, init_belief, actions, d_e, d_gi, d_gh, d_q1, d_q2, d_p_hid, d_p_out,
+                       p_hid, rw_dpre, rw_acts, om_dpre, om_acts, N, B, F) -> None:
+        """Encoder backward, the grouped weight-gradient launch of the world model, its optimiser step."""
+        d, hp = self.d, self.hp
+        HO = d.head_out
         # encoder (+ hoisted projection as its last layer)
         if self.pixel:
             d_emb = self.buf("d_emb", N, d.E)
@@ -1138,12 +1303,12 @@ class DreamerEngine:
         wb.add(d_e, d.Be, self._buf["sv_s"], d.S, N, d.Be, d.S, gWe, d.S + d.A, Gt("fc_embed_state_action.0.bias"))
         wb.add(d_e, d.Be, actions[:-1], d.A, N, d.Be, d.A, gWe[:, d.S:], d.S + d.A)
         wb.add(d_p_hid, d.Hd, feat, F, N, d.Hd, d.Be, Gt("belief_prior.model.0.weight"), d.Be, Gt("belief_prior.model.0.bias"))
-        wb.add(d_p_out, 2 * d.S, p_hid, d.Hd, N, 2 * d.S, d.Hd, Gt("belief_prior.model.2.weight"), d.Hd,
+        wb.add(d_p_out, HO, p_hid, d.Hd, N, HO, d.Hd, Gt("belief_prior.model.2.weight"), d.Hd,
                Gt("belief_prior.model.2.bias"))
         gWq1 = Gt("belief_posterior.model.0.weight")
         wb.add(d_q1, d.Hd, feat, F, N, d.Hd, d.Be, gWq1, d.Be + d.E, Gt("belief_posterior.model.0.bias"))
         wb.add(d_q1, d.Hd, emb, d.E, N, d.Hd, d.E, gWq1[:, d.Be:], d.Be + d.E)
-        wb.add(d_q2, 2 * d.S, self._buf["sv_q"], d.Hd, N, 2 * d.S, d.Hd, Gt("belief_posterior.model.2.weight"), d.Hd,
+        wb.add(d_q2, HO, self._buf["sv_q"], d.Hd, N, HO, d.Hd, Gt("belief_posterior.model.2.weight"), d.Hd,
                Gt("belief_posterior.model.2.bias"))
         dense_sizes = lambda i, o: [i] + [d.Hd] * DENSE_LAYERS + [o]
         self._dense_wgrads(wb, "reward_model", N, rw_dpre, feat, F, rw_acts, dense_sizes(F, 1))
@@ -1159,7 +1324,6 @@ class DreamerEngine:
             torch.cuda.current_stream().wait_event(self._ev_bh_wm_free)
         with self.span("opt_model"):
             self.optimizer_step("model", SLOT_GN_MODEL, hp["model_learning_rate"])
-        return feat
 
     def _behaviour_phase(self, feat: torch.Tensor, noise: Dict[str, torch.Tensor], T: int, B: int,
                          red_ws: torch.Tensor, par: Optional[int]) -> None:
@@ -1179,7 +1343,8 @@ class DreamerEngine:
         ptag = "" if par is None else f"p{par}_"
         if par is not None and self._ev_cr_done[par] is not None:
             torch.cuda.current_stream().wait_event(self._ev_cr_done[par])     # critic of two steps ago: last reader
-        ifeat, ent, act = self.imagine(feat, N, Hm, noise, feat_tag=ptag, split=self.img_split)
+        ifeat, ent, act = self.imagine(feat, N, Hm, noise, feat_tag=ptag, split=self.img_split,
+                                       start_sidx=self._buf[ptag + "sidx"] if d.categorical else None)
         r0 = self._img_split_rows
         with self.span("img_heads_fwd"):
             if not r0:
@@ -1216,27 +1381,34 @@ class DreamerEngine:
         with self.span("img_heads_bwd"):
             self.mlp_backward(Mi, d_r, 1, r_layers, r_acts + [None], None, din0=difeat, ld0=F, w0=F)
             self.mlp_backward(Mi, d_v, 1, v_layers, v_acts + [None], None, din0=difeat, ld0=F, w0=F, accumulate=True)
-        c = cabi.ImagineBwdArgs()
-        c.N, c.Hm, c.Be, c.S, c.A, c.Hd = N, Hm, d.Be, d.S, d.A, d.Hd
+        if d.categorical:
+            c = cabi.ImagineCatBwdArgs()
+            c.N, c.Hm, c.Be, c.D, c.C, c.A, c.Hd = N, Hm, d.Be, d.cat_D, d.cat_C, d.A, d.Hd
+            c.wt_p2 = ptr(pk["p2.T"])
+            c.prior_logits = ptr(self._buf["iprior_logits"])
+        else:
+            c = cabi.ImagineBwdArgs()
+            c.N, c.Hm, c.Be, c.S, c.A, c.Hd = N, Hm, d.Be, d.S, d.A, d.Hd
+            c.wt_p2m, c.wt_p2s = ptr(pk["p2m.T"]), ptr(pk["p2s.T"])
+            c.prior_std, c.eps_prior, c.min_std = ptr(self._buf["iprior_std"]), ptr(noise["img_prior"]), hp["min_std_dev"]
         c.wt_embed_s, c.wt_embed_a = ptr(pk["embed_s.T"]), ptr(pk["embed_a.T"])
         c.wt_ir, c.wt_iz, c.wt_in = ptr(pk["ir.T"]), ptr(pk["iz.T"]), ptr(pk["in.T"])
         c.wt_hr, c.wt_hz, c.wt_hn = ptr(pk["hr.T"]), ptr(pk["hz.T"]), ptr(pk["hn.T"])
-        c.wt_p1, c.wt_p2m, c.wt_p2s = ptr(pk["p1.T"]), ptr(pk["p2m.T"]), ptr(pk["p2s.T"])
+        c.wt_p1 = ptr(pk["p1.T"])
         for l in range(1, DENSE_LAYERS):
             c.wt_a[l - 1] = ptr(pk[f"a{l}.T"])
         c.wt_a4m, c.wt_a4s = ptr(pk["a4m.T"]), ptr(pk["a4s.T"])
-        c.start_feat, c.feat, c.prior_std, c.action = ptr(feat), ptr(ifeat), ptr(self._buf["iprior_std"]), ptr(act)
-        c.eps_action, c.eps_prior = ptr(noise["action"]), ptr(noise["img_prior"])
+        c.start_feat, c.feat, c.action = ptr(feat), ptr(ifeat), ptr(act)
+        c.eps_action = ptr(noise["action"])
         sv_actor = self._buf["sv_actor"]
         c.sv_actor, c.sv_act_stats = ptr(sv_actor), ptr(self._buf["sv_act_stats"])
         c.sv_x, c.sv_gates, c.sv_p = ptr(self._buf["isv_x"]), ptr(self._buf["isv_gates"]), ptr(self._buf["isv_p"])
-        c.min_std = hp["min_std_dev"]
         c.dfeat = ptr(difeat)
         c.dentropy = -hp["entropy_weight"] * inv_mi if hp["entropy_weight"] != -1 else 0.0
         d_apre, d_aout = self.buf("d_actor_pre", DENSE_LAYERS, Mi, d.Hd), self.buf("d_actor_out", Mi, 2 * d.A)
         c.d_actor_pre, c.d_actor_out = ptr(d_apre), ptr(d_aout)
         with self.span("imagine_bwd"):
-            cabi.check(lib.bd_imagine_backward(C.byref(c), st))
+            cabi.check((lib.bd_imagine_cat_backward if d.categorical else lib.bd_imagine_backward)(C.byref(c), st))
         if self.pipeline:       # last reader of the world model in this step
             self._ev_bh_wm_free = torch.cuda.Event()
             self._ev_bh_wm_free.record(torch.cuda.current_stream())
@@ -1259,7 +1431,7 @@ class DreamerEngine:
             self._critic_phase(ifeat, returns, Mi, F, inv_mi, red_ws)
         else:
             torch.cuda.current_stream().wait_stream(self._side)     # join before the next step reuses ifeat / returns
-        self._counts = dict(N=N, Mi=Mi, S=d.S, sum_form=sum_form)
+        self._counts = dict(N=N, Mi=Mi, S=(d.cat_D if d.categorical else d.S), sum_form=sum_form)
 
     def _critic_phase(self, ifeat, returns, Mi: int, F: int, inv_mi: float, red_ws: torch.Tensor) -> None:
         """Critic update (src/dreamer.py:370-391) on the current stream: forward on the detached imagined features,

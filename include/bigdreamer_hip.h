@@ -357,6 +357,104 @@ int bd_kl_categorical_backward(const float* post_logits, const float* prior_logi
                                float kl_balance, float weight, float inv_count, const float* scalars, int slot,
                                float* dpost, float* dprior, void* stream);
 
+/* ---- Categorical RSSM scans: latent_distribution="Categorical" (BASELINE configs[4], algorithm=dreamerV2) ----
+ * TransitionModel.forward (src/models.py:191-299, Categorical branches :226-228,258-260,269-271) and
+ * Dreamer.imagine_ahead (src/dreamer.py:179-237, :205-206,224-227) with CategoricalBeliefModel heads
+ * (src/models.py:76-117): the state is D one-hot factors of C classes, S = D*C (src/planet.py:56-57), sampled with
+ * straight-through gradients (OneHotCategoricalStraightThrough.rsample()).
+ * Same persistent 16-row-tile design as the Gaussian scans.  What changes with the latent:
+ *   - the state is carried as D class indices per row; W [s; a] of the embed layer (and W0 [h; s] of the actor) is the
+ *     MFMA contraction over the action / belief columns PLUS A GATHER of D rows of the transposed state weights
+ *     (`*_sT`: plain row-major [S x out], row k = W[:, k]) -- 32 x out adds instead of a K = 1024 contraction;
+ *   - the head is hidden -> S logits (MFMA, 256 columns at a time through LDS), then per factor softmax and
+ *     sample = argmax(probs / q), q ~ Exp(1): torch.multinomial's single-draw path, q is an explicit input [rows x S];
+ *   - backward: d logits = probs * (g - sum_c probs * g) per factor (straight-through: d state / d probs = I) with
+ *     g = d loss / d state = heads' gradient + W_es^T (d embed pre-activation of the next step) (* nonterminal).
+ * Outputs: feat [rows x (Be+S)] = [h; one-hot s] (dense: the reward / value / decoder chains read it as any other
+ * feature matrix), the class indices sidx [rows x D] (uint8), the logits [rows x S].
+ * C <= 256; S <= 256, or 256 % C == 0 and S % 16 == 0. */
+typedef struct {
+    int T, B, Be, D, C, A, Hd;
+    const float* w_embed_sT;                                   /* plain [S x Be]: row k = W_e[:, k]           */
+    const float* w_embed_a; const float* b_embed;              /* packed (Be, A), [Be]                        */
+    const float* w_ir; const float* w_iz; const float* w_in;
+    const float* w_hr; const float* w_hz; const float* w_hn;
+    const float* b_ih; const float* b_hh;
+    const float* w_q1h; const float* b_q1;                     /* posterior layer 0, belief columns           */
+    const float* w_q2; const float* b_q2;                      /* packed (S, Hd), [S]: posterior logits       */
+    const float* init_belief;                                  /* [B x Be]                                    */
+    const float* init_state;                                   /* [B x S]: zeros, or one-hot per factor       */
+    const float* actions;                                      /* [T x B x A]                                 */
+    const float* nonterm;                                      /* [T x B] or NULL                             */
+    const float* pre_emb;                                      /* [T x B x Hd] hoisted embeddings @ W_q1[:, Be:]^T */
+    const float* q_post;                                       /* [T x B x S] Exp(1) draws of the sampler     */
+    float* feat;                                               /* out [T x B x (Be+S)]                        */
+    float* post_logits;                                        /* out [T x B x S]                             */
+    unsigned char* sidx;                                       /* out [T x B x D] sampled class per factor    */
+    float* sv_s;       /* [T x B x S] masked input state of every step (dense; embed weight gradient), or NULL */
+    float* sv_x; float* sv_gates; float* sv_q;                 /* as bd_observe_fwd_args, or NULL              */
+} bd_observe_cat_fwd_args;
+int bd_observe_cat_forward(const bd_observe_cat_fwd_args* a, void* stream);
+
+typedef struct {
+    int T, B, Be, D, C, A, Hd;
+    const float* wt_embed_s;                                   /* packed transpose (S, Be): d state = W_es^T d pre */
+    const float* wt_ir; const float* wt_iz; const float* wt_in;
+    const float* wt_hr; const float* wt_hz; const float* wt_hn;
+    const float* wt_q1h;                                       /* (Be, Hd)                                    */
+    const float* wt_q2;                                        /* packed transpose (Hd, S)                    */
+    const float* init_belief; const float* nonterm;
+    const float* feat; const float* post_logits;
+    const float* sv_x; const float* sv_gates; const float* sv_q;
+    const float* dfeat;          /* [T x B x (Be+S)] from the obs / reward heads (+ prior head on the belief part) */
+    const float* dpost_logits;   /* [T x B x S] from the KL term, or NULL                                        */
+    float* d_embed_pre; float* d_gi; float* d_gh; float* d_q1_pre;   /* as bd_observe_bwd_args                   */
+    float* d_q2_out;             /* [T x B x S] gradient of the posterior logits                                */
+} bd_observe_cat_bwd_args;
+int bd_observe_cat_backward(const bd_observe_cat_bwd_args* a, void* stream);
+
+typedef struct {
+    int N, Hm, Be, D, C, A, Hd, n_samples;
+    const float* w_embed_sT; const float* w_embed_a; const float* b_embed;
+    const float* w_ir; const float* w_iz; const float* w_in;
+    const float* w_hr; const float* w_hz; const float* w_hn;
+    const float* b_ih; const float* b_hh;
+    const float* w_p1; const float* b_p1;                      /* belief_prior.model.0                        */
+    const float* w_p2; const float* b_p2;                      /* packed (S, Hd), [S]: prior logits           */
+    const float* w_a0h;                                        /* actor layer 0, belief columns, packed       */
+    const float* w_a0sT;                                       /* actor layer 0, state columns: plain [S x Hd] */
+    const float* w_a[3]; const float* b_a[4];
+    const float* w_a4m; const float* w_a4s; const float* b_a4;
+    const float* start_feat;                                   /* [N x (Be+S)] posterior features (one-hot s)  */
+    const unsigned char* start_sidx;                           /* [N x D]                                     */
+    const float* eps_action; const float* eps_entropy;         /* as bd_imagine_fwd_args                      */
+    const float* q_prior;                                      /* [Hm x N x S] Exp(1) draws                   */
+    float act_raw_init_std, act_min_std, act_mean_scale;
+    float* feat;                                               /* out [Hm x N x (Be+S)]                       */
+    unsigned char* sidx;                                       /* out [Hm x N x D]                            */
+    float* prior_logits;                                       /* out [Hm x N x S]                            */
+    float* entropy; float* action;
+    float* sv_actor; float* sv_act_stats; float* sv_x; float* sv_gates; float* sv_p;   /* or NULL            */
+} bd_imagine_cat_fwd_args;
+int bd_imagine_cat_forward(const bd_imagine_cat_fwd_args* a, void* stream);
+
+typedef struct {
+    int N, Hm, Be, D, C, A, Hd;
+    const float* wt_embed_s; const float* wt_embed_a;
+    const float* wt_ir; const float* wt_iz; const float* wt_in;
+    const float* wt_hr; const float* wt_hz; const float* wt_hn;
+    const float* wt_p1;                                        /* (Be, Hd)                                    */
+    const float* wt_p2;                                        /* packed transpose (Hd, S)                    */
+    const float* wt_a[3]; const float* wt_a4m; const float* wt_a4s;
+    const float* start_feat; const float* feat; const float* prior_logits; const float* action;
+    const float* eps_action;
+    const float* sv_actor; const float* sv_act_stats; const float* sv_x; const float* sv_gates; const float* sv_p;
+    const float* dfeat;          /* [Hm x N x (Be+S)] from the reward / value heads                            */
+    float dentropy;
+    float* d_actor_pre; float* d_actor_out;                    /* as bd_imagine_bwd_args                      */
+} bd_imagine_cat_bwd_args;
+int bd_imagine_cat_backward(const bd_imagine_cat_bwd_args* a, void* stream);
+
 /* ---- CEM planner: MPCPlanner.forward (src/planner.py:28-90) -------------------------------------
  * One CEM iteration = bd_plan_rollout + bd_cem_refit.  rows = B * cand candidate action sequences (row = b * cand + c);
  * the rollout forms a_t = act_mean[t][b] + act_std[t][b] * eps_action[t][row] (src/planner.py:60-62), runs the
