@@ -32,18 +32,25 @@ def algorithmic(d):
     """Per-launch algorithmic FLOPs of the persistent kernels and per-step bytes."""
     F = d.Be + d.S
     gru = 2 * 3 * d.Be * d.Be
-    embed = (d.S + d.A) * d.Be
-    prior = d.Be * d.Hd + d.Hd * 2 * d.S
-    actor = F * d.Hd + 3 * d.Hd * d.Hd + d.Hd * 2 * d.A
+    # Categorical latents: the one-hot state enters a first layer as a gather of D rows (D adds per output), not as S MACs
+    s_in = d.cat_D if d.categorical else d.S
+    embed = (s_in + d.A) * d.Be
+    prior = d.Be * d.Hd + d.Hd * d.head_out
+    actor = (d.Be + s_in) * d.Hd + 3 * d.Hd * d.Hd + d.Hd * 2 * d.A
+    F = d.Be + s_in
     img_fwd = 2 * (actor + embed + gru + prior)                   # FLOP per imagined transition
     img_bwd = 2 * (prior + gru + embed + (actor - F * d.Hd))      # layer-0 dgrad is not needed (detached input)
-    obs_fwd = 2 * (embed + gru + d.Be * d.Hd + d.Hd * 2 * d.S)    # posterior hidden (belief half) + head
+    obs_fwd = 2 * (embed + gru + d.Be * d.Hd + d.Hd * d.head_out)  # posterior hidden (belief half) + head
     rows_img = d.Hm * d.N
     flops = {"imagine_fwd": img_fwd * rows_img, "imagine_bwd": img_bwd * rows_img,
              "observe_fwd": obs_fwd * d.N, "observe_bwd": obs_fwd * d.N}
     # SURVEY.md section 8d algorithmic bytes: observe 4*(E+A+1+2S+Be+6S), imagine 4*(101A+2S+Be+3)+66, x3 fwd+bwd
-    obs_b = 4 * (d.E + d.A + 1 + 2 * d.S + d.Be + 6 * d.S)
-    img_b = 4 * (101 * d.A + 2 * d.S + d.Be + 3) + 4 * (d.Be + d.S) / d.Hm
+    if d.categorical:   # per transition: read emb, action, mask, S draws; write belief, D indices (as floats), 2 x S logits
+        obs_b = 4 * (d.E + d.A + 1 + d.S + d.Be + d.cat_D + 2 * d.S)
+        img_b = 4 * (101 * d.A + d.S + d.Be + d.cat_D + 3) + 4 * (d.Be + d.cat_D) / d.Hm
+    else:
+        obs_b = 4 * (d.E + d.A + 1 + 2 * d.S + d.Be + 6 * d.S)
+        img_b = 4 * (101 * d.A + 2 * d.S + d.Be + 3) + 4 * (d.Be + d.S) / d.Hm
     weights = 4 * 1.22e6 + 3 * 4 * 167e3
     step_bytes = 3 * (d.N * obs_b + rows_img * img_b + weights)
     return flops, step_bytes
@@ -54,8 +61,8 @@ def measured_traffic(kernel, kind=""):
     (profiles/*_traffic.json for configs[1], profiles/*_pixel_traffic.json for configs[2]: separate --pmc FETCH_SIZE /
     WRITE_SIZE passes, FETCH_SIZE doubled for gfx950).  None if absent."""
     import glob
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))
-                   if ("_pixel_" in os.path.basename(f)) == (kind == "pixel"))
+    tagged = lambda f: next((k for k in ("pixel", "cat") if f"_{k}_traffic" in os.path.basename(f)), "")
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")) if tagged(f) == kind)
     if not files:
         return None, None
     t = json.load(open(files[-1])).get(kernel)
@@ -210,6 +217,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the surface and pixel-config legs (profiling runs)")
     ap.add_argument("--pixel", action="store_true",
                     help="BASELINE.json configs[2] (64x64 pixel observations, action dim 17) instead of the default configs[1]")
+    ap.add_argument("--categorical", choices=["pixel", "state"], default=None,
+                    help="BASELINE.json configs[4] per GPU: 32x32 Categorical latents (algorithm=dreamerV2), batch 100 = 800/8, "
+                         "64x64 pixel observations with action dim 17 ('pixel') or state observations ('state')")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo: tests only)")
     ap.add_argument("--same-device", action="store_true",
                     help="tests only: every rank on cuda:0 (needs --backend gloo: RCCL refuses two ranks on one device)")
@@ -245,6 +255,9 @@ def main():
     # every blocking stream of the process; the fences are device-wide synchronisations.
     torch.cuda.set_stream(torch.cuda.Stream(dev))
     d = synth.CONFIG3 if args.pixel else synth.CONFIG2
+    if args.categorical:
+        d = synth.CONFIG5 if args.categorical == "pixel" else synth.CONFIG5_STATE
+        args.pixel = bool(d.pixel)
     np.random.seed(rank)
     torch.manual_seed(rank)
     # the host's cyclic garbage collector is parked for the timed loops (a generation-2 pass over the imported modules
@@ -263,9 +276,10 @@ def main():
         # forward: 31.9 of the 63.6 GFLOP of the four scans); every kernel's rate is listed in kernel_tflops
         dom = max((k for k in kt if k in flops), key=lambda k: flops[k])
         ach = flops[dom] / (kt[dom][0] * 1e-3) / 1e12
-        traffic, traffic_src = measured_traffic(dom, "pixel" if args.pixel else "")
+        traffic, traffic_src = measured_traffic(dom, "cat" if args.categorical else ("pixel" if args.pixel else ""))
         out = {
-            "metric": "latent transitions/sec (RSSM + imagination) at batch=50 chunk=50 H=15",
+            "metric": "latent transitions/sec (RSSM + imagination) at batch=50 chunk=50 H=15" if not args.categorical
+            else "latent transitions/sec (RSSM + imagination) at batch=100/GPU chunk=50 H=15, Categorical latents",
             "value": d.transitions_per_step * args.steps * world / dt,
             "unit": "latent transitions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -275,7 +289,11 @@ def main():
             "rccl_ranks": rccl_ranks, "backend": (args.backend if dist_on else None),
             "schedule": ("cross-step pipeline on 3 HIP streams (dynamics learning k+1 | behaviour learning k | critic k)"
                          if eng.pipeline else "serial, one stream"),
-            "config": {"workload": ("BASELINE.json configs[2]: 64x64 pixel-obs Dreamer train_step (conv stacks on "
+            "config": {"workload": (f"BASELINE.json configs[4] per GPU: dreamerV2 {d.cat_D}x{d.cat_C} Categorical latents, "
+                                    + ("64x64 pixel obs, action=17" if d.pixel else "state obs, action=1")
+                                    + f", belief=200 hidden=200 embedding=1024, batch={d.B}/GPU (800/8) chunk=50 H=15")
+                       if args.categorical else
+                       ("BASELINE.json configs[2]: 64x64 pixel-obs Dreamer train_step (conv stacks on "
                                     + ("this library's gather-GEMM kernels" if eng.conv_hip else "MIOpen") + "), "
                                     "belief=200 state=30 hidden=200 embedding=1024 action=17, batch=50/GPU chunk=50 H=15")
                        if args.pixel else
@@ -296,7 +314,7 @@ def main():
         }
     del eng
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not args.no_secondary and not args.pixel:
+    if rank == 0 and world == 1 and not args.no_secondary and not args.pixel and not args.categorical:
         # (a) the same workload through the reference's call surface (Dreamer.train_step, lazy log dicts)
         sms, slogs = surface_ms_per_step(d, dev, args.steps, args.warmup)
         out["surface_ms_per_step"] = sms

@@ -31,12 +31,14 @@ def _hp_from_params(params: Dict[str, Any]) -> Dict[str, float]:
 
 
 class Dreamer:
-    """Drop-in for the reference's ``Dreamer`` (state observations, Gaussian latents)."""
+    """Drop-in for the reference's ``Dreamer``: state or 64x64 pixel observations, Gaussian or Categorical latents
+    (``latent_distribution``; Categorical: state_size = dimensions * classes, src/planet.py:56-57)."""
 
     def __init__(self, params: Dict[str, Any], env, device: Optional[str] = None, world_size: int = 1,
                  process_group=None):
-        if params.get("latent_distribution", "Gaussian") != "Gaussian":
-            raise NotImplementedError("Categorical latents: the reference path crashes at HEAD (parity unpinned)")
+        self.latent_distribution = params.get("latent_distribution", "Gaussian")
+        if self.latent_distribution not in ("Gaussian", "Categorical"):
+            raise NotImplementedError(f"{self.latent_distribution}  is yet yet implemented")     # as src/dreamer.py:108
         if params["ActorCritic"]["gradient_mixing"] != -1:
             raise NotImplementedError("gradient_mixing not yet implemented ")      # as src/dreamer.py:339
         if params.get("use_discount", False):
@@ -48,6 +50,10 @@ class Dreamer:
         self.params = params
         self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
         self.belief_size, self.state_size = params["belief_size"], params["state_size"]
+        cat_D = cat_C = 0
+        if self.latent_distribution == "Categorical":
+            cat_D, cat_C = int(params["discrete_latent_dimensions"]), int(params["discrete_latent_classes"])
+            self.state_size = cat_D * cat_C                                                    # src/planet.py:56-57
         self.action_size, self.hidden_size = env.action_size, params["hidden_size"]
         self.embedding_size = params["embedding_size"]
         self.batch_size, self.seq_len = params["batch_size"], params["seq_len"]
@@ -59,7 +65,7 @@ class Dreamer:
         obs_size = 3 * 64 * 64 if self.pixel_observation else env.observation_size
         self.dims = Dims(B=self.batch_size, L=self.seq_len, H=self.planning_horizon, Be=self.belief_size,
                          S=self.state_size, Hd=self.hidden_size, E=self.embedding_size, A=self.action_size,
-                         O=obs_size, pixel=self.pixel_observation)
+                         O=obs_size, pixel=self.pixel_observation, cat_D=cat_D, cat_C=cat_C)
         self.engine = DreamerEngine(self.dims, _hp_from_params(params), self.device, world_size=world_size,
                                     process_group=process_group)
         e = self.engine
@@ -84,7 +90,9 @@ class Dreamer:
         for g in ("model", "actor", "critic", "critic_target"):
             e.pack(g)
         self.transition_model = TransitionModel(self.belief_size, self.state_size, self.action_size, self.hidden_size,
-                                                self.embedding_size, engine=e)
+                                                self.embedding_size, latent_distribution=self.latent_distribution,
+                                                discrete_latent_dimensions=cat_D or 32, discrete_latent_classes=cat_C or 32,
+                                                engine=e)
         if px:
             self.observation_model = ObservationModel(self.belief_size, self.state_size, E, engine=e)
             self.encoder = CnnImageEncoder(E, engine=e)
@@ -188,12 +196,20 @@ class Dreamer:
         Hm = self.planning_horizon - 1
         noise = _noise or {"action": torch.randn(Hm, N, d.A, device=e.dev),
                            "entropy": torch.randn(Hm, d.n_entropy, N, d.A, device=e.dev),
-                           "img_prior": torch.randn(Hm, N, d.S, device=e.dev)}
+                           "img_prior": self._state_draw(Hm, N)}
         ifeat, ent, _ = e.imagine(start, N, Hm, noise, save=False, tag="api_")
         f = ifeat.view(Hm, N, d.Be + d.S)
-        pm = e._buf["api_iprior_mean"].view(Hm, N, d.S).clone()
-        ps = e._buf["api_iprior_std"].view(Hm, N, d.S).clone()
-        return f[..., :d.Be].clone(), f[..., d.Be:].clone(), (pm, ps), ent.view(Hm, N).clone()
+        if d.categorical:
+            params = (e._buf["api_iprior_logits"].view(Hm, N, d.cat_D, d.cat_C).clone(),)
+        else:
+            params = (e._buf["api_iprior_mean"].view(Hm, N, d.S).clone(), e._buf["api_iprior_std"].view(Hm, N, d.S).clone())
+        return f[..., :d.Be].clone(), f[..., d.Be:].clone(), params, ent.view(Hm, N).clone()
+
+    def _state_draw(self, steps: int, rows: int) -> Tensor:
+        """Noise of one state sample per row: standard normals (Gaussian latents) or the sampler's Exp(1) variates per
+        class (Categorical; the one-step get_action path never looks at them)."""
+        t = torch.empty(steps, rows, self.dims.S, device=self.engine.dev)
+        return t.exponential_() if self.dims.categorical else t.normal_()
 
     @torch.no_grad()
     def get_action(self, belief: Tensor, state: Tensor, deterministic: bool = False,
@@ -216,13 +232,13 @@ class Dreamer:
             noise = {"action": torch.zeros(1, N, d.A, device=e.dev),
                      "entropy": (nz["entropy"].to(e.dev).float().reshape(1, d.n_entropy, N, d.A) if "entropy" in nz
                                  else torch.randn(1, d.n_entropy, N, d.A, device=e.dev)),
-                     "img_prior": torch.zeros(1, N, d.S, device=e.dev)}
+                     "img_prior": torch.ones(1, N, d.S, device=e.dev)}
             _, ent, _ = e.imagine(start, N, 1, noise, save=False, tag="act_")
             return action, ent.view(N).clone()
         start = torch.cat([belief, state], dim=1).contiguous().float()
         noise = _noise or {"action": torch.randn(1, N, d.A, device=e.dev),
                            "entropy": torch.randn(1, d.n_entropy, N, d.A, device=e.dev),
-                           "img_prior": torch.randn(1, N, d.S, device=e.dev)}
+                           "img_prior": torch.ones(1, N, d.S, device=e.dev)}       # the unused prior sample's draws
         _, ent, act = e.imagine(start, N, 1, noise, save=False, tag="act_")   # one step: actor + sample (+ unused prior)
         return act.view(N, d.A).clone(), ent.view(N).clone()
 
@@ -242,7 +258,7 @@ class Dreamer:
         belief, posterior_state = belief.squeeze(dim=0), posterior_state.squeeze(dim=0)
         action, _ = self.get_action(belief, posterior_state, _noise=None if nz is None else {
             "action": nz["action"].unsqueeze(0).contiguous(), "entropy": nz["entropy"].unsqueeze(0).contiguous(),
-            "img_prior": torch.zeros(1, belief.shape[0], self.state_size, device=self.device)})
+            "img_prior": torch.ones(1, belief.shape[0], self.state_size, device=self.device)})
         if explore:
             eps = torch.randn_like(action) if nz is None else nz["explore"]
             action = torch.clamp(action + self.action_noise * eps, -1, 1)
@@ -252,8 +268,8 @@ class Dreamer:
 
 
 class DreamerV2(Dreamer):
-    """src/dreamerV2.py:13-25: Dreamer with the V2 KL settings (balanced KL; kl_loss_weight 1.0 is replaced by
-    0.1).  Gaussian latents only -- the reference's Categorical path crashes at HEAD."""
+    """src/dreamerV2.py:13-25: Dreamer with the V2 KL settings (balanced KL; kl_loss_weight 1.0 is replaced by 0.1);
+    ``latent_distribution=Categorical`` selects the 32 x 32 discrete latents (BASELINE configs[4])."""
 
     def __init__(self, params: Dict[str, Any], env, **kw):
         p = dict(params)
@@ -322,10 +338,14 @@ def _ref_init_decoder(feat: int, E: int) -> torch.nn.Module:
 
 def _ref_init_transition(d: Dims) -> torch.nn.Module:
     from torch import nn
-    from .models import GaussianBeliefHolder
+    from .models import CategoricalBeliefHolder, GaussianBeliefHolder
     m = nn.Module()
     m.rnn = nn.GRUCell(d.Be, d.Be)
     m.fc_embed_state_action = nn.Sequential(nn.Linear(d.S + d.A, d.Be), nn.ELU())
-    m.belief_prior = GaussianBeliefHolder(d.Be, d.Hd, d.S, 0.1)
-    m.belief_posterior = GaussianBeliefHolder(d.Be + d.E, d.Hd, d.S, 0.1)
+    if d.categorical:
+        m.belief_prior = CategoricalBeliefHolder(d.Be, d.Hd, d.cat_D, d.cat_C)
+        m.belief_posterior = CategoricalBeliefHolder(d.Be + d.E, d.Hd, d.cat_D, d.cat_C)
+    else:
+        m.belief_prior = GaussianBeliefHolder(d.Be, d.Hd, d.S, 0.1)
+        m.belief_posterior = GaussianBeliefHolder(d.Be + d.E, d.Hd, d.S, 0.1)
     return m

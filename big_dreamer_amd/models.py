@@ -77,24 +77,46 @@ class GaussianBeliefHolder(nn.Module):
                                    nn.Identity())
 
 
+class CategoricalBeliefHolder(nn.Module):
+    """Parameter container of CategoricalBeliefModel (src/models.py:76-100): build_mlp(in, hidden, D*C, 1) ->
+    ``model.0``, ``model.2``."""
+
+    def __init__(self, input_size: int, hidden_size: int, discrete_latent_dimensions: int, discrete_latent_classes: int):
+        super().__init__()
+        self.discrete_latent_dimensions = discrete_latent_dimensions
+        self.discrete_latent_classes = discrete_latent_classes
+        self.dim = discrete_latent_classes * discrete_latent_dimensions
+        self.model = nn.Sequential(nn.Linear(input_size, hidden_size), nn.ELU(), nn.Linear(hidden_size, self.dim),
+                                   nn.Identity())
+
+
 class TransitionModel(_EngineBacked):
-    """src/models.py:120-299 (Gaussian latents).  ``forward`` returns the reference's 5-tuple."""
+    """src/models.py:120-299.  ``forward`` returns the reference's 5-tuple; with latent_distribution="Categorical" the
+    params are the 1-tuples ``(logits (T, B, D, C),)`` the reference intends (it stores the tuple itself in its
+    per-step lists and crashes in ``stack`` at HEAD, src/models.py:259-260,270-271,295)."""
 
     def __init__(self, belief_size: int, state_size: int, action_size: int, hidden_size: int, embedding_size: int,
                  activation: Optional[str] = "ELU", min_std_dev: float = 0.1,
                  latent_distribution: Optional[str] = "Gaussian", discrete_latent_dimensions: Optional[int] = 32,
                  discrete_latent_classes: Optional[int] = 32, *, engine: DreamerEngine):
         super().__init__()
-        if latent_distribution != "Gaussian":
-            # the reference's Categorical path crashes at HEAD (src/models.py:284; SURVEY.md section 8c)
-            raise NotImplementedError("latent_distribution='Categorical' is not implemented (parity unpinned)")
+        assert latent_distribution in ["Gaussian", "Categorical"], f"{latent_distribution}"      # src/models.py:144
         assert activation == "ELU"
         self.min_std_dev = min_std_dev
         self.latent_distribution = latent_distribution
         self.rnn = nn.GRUCell(belief_size, belief_size)
         self.fc_embed_state_action = nn.Sequential(nn.Linear(state_size + action_size, belief_size), nn.ELU())
-        self.belief_prior = GaussianBeliefHolder(belief_size, hidden_size, state_size, min_std_dev)
-        self.belief_posterior = GaussianBeliefHolder(belief_size + embedding_size, hidden_size, state_size, min_std_dev)
+        if latent_distribution == "Gaussian":
+            self.belief_prior = GaussianBeliefHolder(belief_size, hidden_size, state_size, min_std_dev)
+            self.belief_posterior = GaussianBeliefHolder(belief_size + embedding_size, hidden_size, state_size, min_std_dev)
+            self._cat = None
+        else:
+            D, Cc = discrete_latent_dimensions, discrete_latent_classes
+            assert state_size == D * Cc, "Categorical latents: state_size = dimensions * classes (src/planet.py:56-57)"
+            assert engine.d.categorical and (engine.d.cat_D, engine.d.cat_C) == (D, Cc)
+            self.belief_prior = CategoricalBeliefHolder(belief_size, hidden_size, D, Cc)
+            self.belief_posterior = CategoricalBeliefHolder(belief_size + embedding_size, hidden_size, D, Cc)
+            self._cat = (D, Cc)
         self._dims = (belief_size, state_size, action_size, hidden_size, embedding_size)
         self._bind(engine, "transition_model", "model")
 
@@ -109,27 +131,32 @@ class TransitionModel(_EngineBacked):
         T, B = actions.shape[0], actions.shape[1]
         M = T * B
         f = lambda t: t.contiguous().float()
+        cat = self._cat
+        # state draws: standard normals, or -- Categorical -- the sampler's Exp(1) variates per class (T, B, D*C)
+        draw = (lambda: torch.empty(T, B, S, device=eng.dev).exponential_()) if cat else \
+            (lambda: torch.randn(T, B, S, device=eng.dev))
+        params = (lambda a, b: (a.clone().view(T, B, cat[0], cat[1]),)) if cat else (lambda a, b: (v(a), v(b)))
         if embeddings is None:
             # prior-only rollout (src/models.py:241,296-297; the MPC planner's call, src/planner.py:65): the sampled
             # prior state is fed back; posterior outputs are None
-            eps_p = torch.randn(T, B, S, device=eng.dev) if _noise is None else f(_noise[0])
+            eps_p = draw() if _noise is None else f(_noise[0])
             feat, pm, ps = eng.observe(f(actions), None if nonterminals is None else f(nonterminals), None, eps_p,
                                        f(init_belief), f(init_state), T, B, save=False, tag="api_", prior_only=True)
             feat = feat.view(T, B, Be + S)
             v = lambda t: t.clone().view(T, B, S)
-            return feat[..., :Be].clone(), feat[..., Be:].clone(), (v(pm), v(ps)), None, None
+            return feat[..., :Be].clone(), feat[..., Be:].clone(), params(pm, ps), None, None
         pre = eng.buf("api_pre_emb", M, Hd)
         eng.mlp_forward(M, f(embeddings).view(M, E), E, E, [("q1e", None, Hd, E, 0)], None, pre, Hd)
         if _noise is None:      # (prior eps, posterior eps); the parity tests inject the oracle's draws
-            eps_p, eps_q = torch.randn(T, B, S, device=eng.dev), torch.randn(T, B, S, device=eng.dev)
+            eps_p, eps_q = draw(), draw()
         else:
             eps_p, eps_q = f(_noise[0]), f(_noise[1])
         feat, qm, qs = eng.observe(f(actions), None if nonterminals is None else f(nonterminals), pre, eps_q,
                                    f(init_belief), f(init_state), T, B, save=False, tag="api_")
-        pst, pm, ps = eng.prior_head(feat, M, eps_p, tag="api_")
+        pst, pm, ps = eng.prior_head(feat, M, eps_p.view(M, S) if cat else eps_p, tag="api_")
         feat = feat.view(T, B, Be + S)
         v = lambda t: t.clone().view(T, B, S)
-        return (feat[..., :Be].clone(), v(pst), (v(pm), v(ps)), feat[..., Be:].clone(), (v(qm), v(qs)))
+        return (feat[..., :Be].clone(), v(pst), params(pm, ps), feat[..., Be:].clone(), params(qm, qs))
 
 
 class ActorModel(_EngineBacked):

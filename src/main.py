@@ -44,7 +44,9 @@ def my_app(argv):
     dev = model.device
     observation = env.reset()
     belief = torch.zeros(1, params["belief_size"], device=dev)
-    posterior_state = torch.zeros(1, params["state_size"], device=dev)
+    # (the reference sizes this with params["state_size"], src/main.py:94, which is wrong for Categorical latents, where
+    # the agent's state_size is dimensions * classes, src/planet.py:56-57)
+    posterior_state = torch.zeros(1, model.state_size, device=dev)
     action = torch.zeros(1, env.action_size, device=dev)
     logs, episode_reward, past = {}, 0.0, time.time()
     for step in range(env_steps, params["train_steps"]):

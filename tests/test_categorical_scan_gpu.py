@@ -137,3 +137,113 @@ def test_categorical_train_steps_vs_oracle_and_golden(name):
                     compare_tensor(g, f"step{step}.param.{mod}.{k}", got, full, atol=2e-5, rtol=1e-5)
     finally:
         print("\n".join(rep[-400:]))
+
+
+def test_categorical_surface_matches_oracle():
+    """The drop-in surface with latent_distribution=Categorical: Dreamer(params, env) builds (state_size = D*C,
+    src/planet.py:56-57), TransitionModel.forward returns 1-tuples of (T, B, D, C) logits, imagine_ahead / get_action /
+    update_belief_and_act run on the Categorical kernels, train_step returns the reference's log keys."""
+    from big_dreamer_amd.config import load_config
+    from big_dreamer_amd.dreamer import DreamerV2
+    from oracle import dreamer_oracle as O
+    d = synth.CAT_32
+    seed = 61
+
+    class Env:
+        action_size, observation_size = d.A, d.O
+
+        def step(self, a):
+            return torch.zeros(1, d.O), 0.0, False
+
+    params = load_config([f"belief_size={d.Be}", "state_size=30", f"hidden_size={d.Hd}", f"embedding_size={d.E}",
+                          f"batch_size={d.B}", f"seq_len={d.L}", f"planning_horizon={d.H}", "experience_size=200",
+                          "algorithm=dreamerV2", "latent_distribution=Categorical", f"discrete_latent_dimensions={d.cat_D}",
+                          f"discrete_latent_classes={d.cat_C}"])
+    agent = DreamerV2(params, Env())
+    assert agent.state_size == d.S and agent.transition_model.latent_distribution == "Categorical"
+    P = synth.make_params(d, seed)
+    for mod in ("transition_model", "observation_model", "reward_model", "encoder", "actor", "critic", "critic_target"):
+        m = getattr(agent, mod)
+        assert list(m.state_dict().keys()) == [n for n, _ in synth.param_shapes(d)[mod if mod != "critic_target" else "critic"]]
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in P[mod].items()})
+    tP = {m: {k: torch.tensor(v) for k, v in sd.items()} for m, sd in P.items()}
+    batch, noise = synth.make_batch(d, seed), synth.make_noise(d, seed)
+    tb = {k: torch.tensor(v) for k, v in batch.items()}
+    cu = lambda x: torch.as_tensor(x).cuda()
+    cat = (d.cat_D, d.cat_C)
+    emb = agent.encoder(cu(batch["observations"][1:]))
+    want_emb = O.mlp(tb["observations"][1:], tP["encoder"])
+    out = agent.transition_model(torch.zeros(d.B, d.S).cuda(), cu(batch["actions"][:-1]), torch.zeros(d.B, d.Be).cuda(), emb,
+                                 cu(batch["nonterminals"][:-1]), _noise=(cu(noise["obs_prior"]), cu(noise["obs_post"])))
+    want = O.transition_forward(tP["transition_model"], torch.zeros(d.B, d.S), tb["actions"][:-1], torch.zeros(d.B, d.Be),
+                                want_emb, tb["nonterminals"][:-1], torch.tensor(noise["obs_prior"]),
+                                torch.tensor(noise["obs_post"]), cat)
+    assert len(out[2]) == 1 and len(out[4]) == 1 and tuple(out[2][0].shape) == (d.T, d.B, d.cat_D, d.cat_C)
+    assert_close("beliefs", out[0].cpu().numpy(), want[0].numpy(), 2e-5, 2e-5)
+    assert np.array_equal(out[1].cpu().numpy(), want[1].numpy()), "prior states"
+    assert np.array_equal(out[3].cpu().numpy(), want[3].numpy()), "posterior states"
+    assert_close("prior logits", out[2][0].cpu().numpy(), want[2][0].numpy(), 2e-5, 2e-5)
+    assert_close("posterior logits", out[4][0].cpu().numpy(), want[4][0].numpy(), 2e-5, 2e-5)
+    # prior-only rollout (embeddings=None): the sampled prior state is fed back
+    pout = agent.transition_model(torch.zeros(d.B, d.S).cuda(), cu(batch["actions"][:-1]), torch.zeros(d.B, d.Be).cuda(), None,
+                                  None, _noise=(cu(noise["obs_prior"]), None))
+    pwant = O.transition_forward(tP["transition_model"], torch.zeros(d.B, d.S), tb["actions"][:-1], torch.zeros(d.B, d.Be),
+                                 None, None, torch.tensor(noise["obs_prior"]), None, cat)
+    assert pout[3] is None and pout[4] is None
+    assert np.array_equal(pout[1].cpu().numpy(), pwant[1].numpy()) and len(pout[2]) == 1
+    assert_close("prior-only beliefs", pout[0].cpu().numpy(), pwant[0].numpy(), 2e-5, 2e-5)
+    # imagine_ahead from the posteriors
+    nz = {"action": cu(noise["action"]), "entropy": cu(noise["entropy"]), "img_prior": cu(noise["img_prior"])}
+    ib, is_, (il,), ent = agent.imagine_ahead(out[3], out[0], _noise=nz)
+    wb, ws, (wl,), went = O.imagine_ahead(tP, want[3], want[0], d.H, torch.tensor(noise["action"]),
+                                          torch.tensor(noise["entropy"]), torch.tensor(noise["img_prior"]), cat)
+    assert tuple(il.shape) == (d.Hm, d.N, d.cat_D, d.cat_C)
+    assert_close("imagine beliefs", ib.cpu().numpy(), wb.numpy(), 5e-5, 5e-5)
+    assert np.array_equal(is_.cpu().numpy(), ws.numpy())
+    assert_close("entropy", ent.cpu().numpy(), went.numpy(), 2e-2, 1e-3)
+    # one collect-loop decision from the all-zero start state (src/main.py:91-95), then one from the sampled state
+    belief, state = torch.zeros(1, d.Be).cuda(), torch.zeros(1, agent.state_size).cuda()
+    action = torch.zeros(1, d.A).cuda()
+    for _ in range(2):
+        belief, state, action, _, _, _ = agent.update_belief_and_act(Env(), belief, state, action, torch.zeros(1, d.O),
+                                                                    explore=True)
+        assert tuple(state.shape) == (1, d.S) and float(state.sum()) == d.cat_D and float(action.abs().max()) <= 1.0
+    # train_step through the surface
+    rep = synth.make_replay(d, rows=200, seed=2)
+    for k, v in rep.items():
+        getattr(agent.buffer, k)[:] = v
+    agent.buffer.idx, agent.buffer.full = 0, True
+    np.random.seed(0)
+    logs = agent.train_step()
+    assert set(logs.keys()) == {"observation_loss", "reward_loss", "kl_loss", "model_loss", "actor_loss", "policy_entropy",
+                                "value_loss"}
+    assert all(np.isfinite(float(v)) for v in logs.values())
+
+
+def test_categorical_full_size_step_vs_oracle():
+    """BASELINE configs[4] per GPU at full size on state observations: 32 x 32 latents, batch 100 (= 800 / 8), chunk 50,
+    H 15, belief / hidden 200, embedding 1024 -- one whole train step against the oracle (no reference run at this size:
+    losses, gradient norms, every weight after Adam)."""
+    from big_dreamer_amd.engine import DreamerEngine
+    from oracle import dreamer_oracle as O
+    d = synth.CONFIG5_STATE
+    P, batch, nz = synth.make_params(d, 71), synth.make_batch(d, 71), synth.make_noise(d, 71)
+    torch.set_num_threads(16)
+    od = O.OracleDreamer(P, dict(planning_horizon=d.H, categorical=(d.cat_D, d.cat_C), free_nats=0.0))
+    eng = DreamerEngine(d, dict(free_nats=0.0), "cuda", params=P)
+    ologs = od.train_step(batch, nz)
+    logs = eng.train_step(_dev(batch), _dev(nz))
+    torch.cuda.synchronize()
+    rep = []
+    try:
+        for k, v in ologs.items():
+            tol = (5e-4, 5e-4) if k in ("policy_entropy", "actor_loss") else (2e-5, 5e-5)
+            _rel(k, logs[k], v, tol[0], tol[1], rep)
+        gn = od.last["grad_norms"]
+        _rel("grad_norms", [logs["grad_norm_model"], logs["grad_norm_actor"], logs["grad_norm_critic"]],
+             [gn["model"], gn["actor"], gn["critic"]], 1e-6, 2e-3, rep)
+        for mod in list(O.MODEL_MODULES) + ["actor", "critic"]:
+            for k, p in od.P[mod].items():
+                _rel(f"param.{mod}.{k}", eng.W(mod, k).cpu().numpy(), p.detach().numpy(), 2e-5, 1e-5, rep)
+    finally:
+        print("\n".join(rep[-80:]))
