@@ -38,7 +38,8 @@ class Layer(C.Structure):
 
 class MlpFwdArgs(C.Structure):
     _fields_ = [("M", I32), ("in0", P), ("ld0", I32), ("w0", I32), ("in1", P), ("ld1", I32), ("w1", I32),
-                ("n_layers", I32), ("layer", Layer * BD_MAX_LAYERS), ("out", P), ("ldo", I32)]
+                ("n_layers", I32), ("layer", Layer * BD_MAX_LAYERS), ("out", P), ("ldo", I32),
+                ("gidx", P), ("gWT", P), ("gD", I32), ("gC", I32)]
 
 
 class LayerBwd(C.Structure):

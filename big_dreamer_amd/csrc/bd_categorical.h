@@ -104,6 +104,171 @@ __device__ __forceinline__ void cat_jacobian(const CatGeo& g, const float* __res
     }
 }
 
+// The same with everything in REGISTERS (compile-time C, C % 4 == 0): logits and g from the chunk images, the direct
+// logit gradient and the output as 16-byte global accesses (a thread's C values are contiguous), the result also into the
+// fragment tile dLf of the chunk's K blocks.  dextra / dout: this (row, factor)'s first class, or null.
+template <int CC>
+__device__ __forceinline__ void cat_jacobian_reg(const CatGeo& g, const float* __restrict__ lg, const float* __restrict__ gimg,
+                                                 int row, int fl, bool valid, const float* __restrict__ dextra,
+                                                 float* __restrict__ dout, float* __restrict__ dLf) {
+    float v[CC], gr[CC];
+    floatx4 ex[CC / 4];
+#pragma unroll
+    for (int c = 0; c < CC; c += 4)
+        ex[c / 4] = (dextra && valid) ? *reinterpret_cast<const floatx4*>(dextra + c) : floatx4{0.f, 0.f, 0.f, 0.f};
+    const int rot = fl % CC;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+        int r = c + rot;
+        if (r >= CC) r -= CC;
+        v[c] = lg[row * g.ld + fl * CC + r];
+        gr[c] = gimg[row * g.ld + fl * CC + r];
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) m = fmaxf(m, v[c]);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) s += expf(v[c] - m);
+    const float lse = m + logf(s);
+    const float m2 = m - lse;
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+        v[c] = expf((v[c] - lse) - m2);
+        s2 += v[c];
+    }
+    const float inv = 1.f / s2;
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+        v[c] *= inv;
+        dot += v[c] * gr[c];
+    }
+#pragma unroll
+    for (int c = 0; c < CC; c += 4) {
+        floatx4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = valid ? v[c + j] * (gr[c + j] - dot) + ex[c / 4][j] : 0.f;
+            dLf[frag_idx(row, fl * CC + c + j)] = o[j];
+        }
+        if (dout && valid) *reinterpret_cast<floatx4*>(dout + c) = o;
+    }
+}
+
+// Full-width image (forward heads: all S logits of the tile at once, row stride S + 8): same swizzle, fl = global factor.
+struct CatFull {
+    int D, C, S, ld;
+    __host__ __device__ CatFull(int D_, int C_) : D(D_), C(C_), S(D_ * C_), ld(cdiv(D_ * C_, 16) * 16 + 8) {}
+    __host__ __device__ int image_floats() const { return 16 * ld; }
+    __device__ __forceinline__ int addr(int row, int f, int c) const {
+        int r = c + f % C;
+        if (r >= C) r -= C;
+        return row * ld + f * C + r;
+    }
+};
+
+// One (row, factor) with the C logits and the C draws in REGISTERS (compile-time C): same operations, same order as
+// cat_sample; the draws come straight from global memory as 16-byte loads (a thread's C draws are contiguous).
+template <int CC>
+__device__ __forceinline__ int cat_sample_reg(const CatFull& g, const float* __restrict__ lg, const float* __restrict__ qrow,
+                                              int row, int f) {
+    float v[CC], q[CC];
+    if constexpr (CC % 4 == 0) {
+#pragma unroll
+        for (int c = 0; c < CC; c += 4) {
+            const floatx4 t = *reinterpret_cast<const floatx4*>(qrow + c);
+            q[c] = t[0]; q[c + 1] = t[1]; q[c + 2] = t[2]; q[c + 3] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) q[c] = qrow[c];
+    }
+    int rot = f % CC;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+        int r = c + rot;
+        if (r >= CC) r -= CC;
+        v[c] = lg[row * g.ld + f * CC + r];
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) m = fmaxf(m, v[c]);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) s += expf(v[c] - m);
+    const float lse = m + logf(s);
+    const float m2 = m - lse;
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+        v[c] = expf((v[c] - lse) - m2);
+        s2 += v[c];
+    }
+    float best = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+        const float r = (v[c] / s2) / q[c];
+        if (r > best) { best = r; arg = c; }
+    }
+    return arg;
+}
+
+// generic C: logits from the image, draws from global memory
+__device__ __forceinline__ int cat_sample_any(const CatFull& g, const float* __restrict__ lg, const float* __restrict__ qrow,
+                                              int row, int f) {
+    float m = -INFINITY;
+    for (int c = 0; c < g.C; ++c) m = fmaxf(m, lg[g.addr(row, f, c)]);
+    float s = 0.f;
+    for (int c = 0; c < g.C; ++c) s += expf(lg[g.addr(row, f, c)] - m);
+    const float lse = m + logf(s);
+    const float m2 = m - lse;
+    float s2 = 0.f;
+    for (int c = 0; c < g.C; ++c) s2 += expf((lg[g.addr(row, f, c)] - lse) - m2);
+    float best = -INFINITY;
+    int arg = 0;
+    for (int c = 0; c < g.C; ++c) {
+        const float r = (expf((lg[g.addr(row, f, c)] - lse) - m2) / s2) / qrow[c];
+        if (r > best) { best = r; arg = c; }
+    }
+    return arg;
+}
+
+// The head, forward, whole width at once: ONE contraction over all S/16 column blocks into the image (8 blocks per wave
+// at 32 x 32: a deep software pipeline, no per-chunk barriers), then every thread samples one (row, factor).
+// q_row0: first of 16 consecutive global rows of the sampler's draws (row stride S).  Ends with a workgroup barrier.
+__device__ __forceinline__ void cat_head_forward_full(const CatFull& g, const float* __restrict__ hid, int Kb_hd,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      const float* __restrict__ q_row0, float* __restrict__ logits_row0,
+                                                      int rows_valid, float* __restrict__ lg, int* __restrict__ sidx_l) {
+    const int lane = bd_tid() & 63;
+    const Seg seg[1] = {{hid, w2, Kb_hd}};
+    tile_linear_g<1, 1>(seg, b2, g.S, [&](int, int nb, floatx4 acc) {
+        const int col = nb * 16 + (lane & 15);
+        if (col >= g.S) return;
+        const int f = col / g.C, c = col - f * g.C;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * (lane >> 4) + r;
+            lg[g.addr(row, f, c)] = acc[r];
+            if (logits_row0 && row < rows_valid) logits_row0[(size_t)row * g.S + col] = acc[r];
+        }
+    });
+    lds_barrier();
+    for (int i = bd_tid(); i < 16 * g.D; i += blockDim.x) {
+        const int row = i / g.D, f = i - row * g.D;
+        int arg = 0;
+        if (row < rows_valid) {
+            const float* qrow = q_row0 + (size_t)row * g.S + f * g.C;
+            arg = g.C == 32 ? cat_sample_reg<32>(g, lg, qrow, row, f) : cat_sample_any(g, lg, qrow, row, f);
+        }
+        sidx_l[i] = arg;
+    }
+    lds_barrier();
+}
+
 // The head, forward: logits = hid W2^T + b2 chunk by chunk; `logit_row(row)` gives the global row base of the logits
 // output (or nullptr), `q_row0` the first of 16 consecutive global rows of the sampler's draws (row stride S).
 // Fills sidx_l[16][D] (int) with the sampled classes.  Ends with a workgroup barrier.

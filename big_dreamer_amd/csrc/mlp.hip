@@ -16,19 +16,44 @@ __global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, in
     float* cur = smem;                                   // inputs of even layers
     float* nxt = smem + (size_t)RT * KbA * kFragFloats;  // inputs of odd layers
     float* scratch = nxt + (size_t)RT * KbB * kFragFloats;   // split-K partials for narrow layers
+    float* xs = scratch + kSplitScratchFloats;               // [16*RT][N0] gathered one-hot columns of layer 0 (gD > 0)
     load_tile_concat<RT>(cur, cdiv(a.w0 + a.w1, 16), row0, a.M, a.in0, a.ld0, a.w0, a.in1, a.ld1, a.w1);
+    if (a.gD > 0) {       // layer 0's one-hot input segment: sum of gD rows of the transposed weights per row
+        const int N0 = a.layer[0].N, N4 = N0 >> 2;           // N0 % 4 == 0 (host)
+        for (int i = bd_tid(); i < 16 * RT * N4; i += blockDim.x) {
+            const int row = i / N4, c4 = i - row * N4;
+            const int grow = row0 + row;
+            floatx4 s = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (grow < a.M) {
+                const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(a.gWT) + c4;
+                const unsigned char* __restrict__ ix = a.gidx + (size_t)grow * a.gD;
+                int f = 0;
+                for (; f + 8 <= a.gD; f += 8) {
+                    floatx4 t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[j] = W4[(size_t)((f + j) * a.gC + ix[f + j]) * N4];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s += t[j];
+                }
+                for (; f < a.gD; ++f) s += W4[(size_t)(f * a.gC + ix[f]) * N4];
+            }
+            reinterpret_cast<floatx4*>(xs)[i] = s;
+        }
+    }
     lds_barrier();
     for (int l = 0; l < a.n_layers; ++l) {
         const bd_layer L = a.layer[l];
         const bool last = (l == a.n_layers - 1);
         const int Kb = cdiv(L.K, 16), Nb = cdiv(L.N, 16);
+        const bool gather0 = l == 0 && a.gD > 0;
         tile_linear<RT, NI>(cur, Kb, L.w, L.bias, L.N, [&](int rt, int nb, floatx4 acc) {
             const int c = lane & 15, col = nb * 16 + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * (lane >> 4) + r;
                 const int grow = row0 + rt * 16 + row;
-                const float v = act_apply(L.act, acc[r]);
+                const float pre = (gather0 && col < L.N) ? acc[r] + xs[(rt * 16 + row) * L.N + col] : acc[r];
+                const float v = act_apply(L.act, pre);
                 if (!last) nxt[(rt * Nb + nb) * kFragFloats + ((c >> 2) * 16 + row) * 4 + (c & 3)] = v;
                 if (grow < a.M && col < L.N) {
                     if (L.save) L.save[(size_t)grow * L.N + col] = v;
@@ -121,8 +146,9 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_kernel(bd_mlp_bwd_args a, in
 }
 
 template <class K, class Args>
-static int launch_chain(K kernel, const char* name, int M, int RT, int KbA, int KbB, hipStream_t s, const Args& args) {
-    const size_t lds = ((size_t)RT * (KbA + KbB) * kFragFloats + kSplitScratchFloats) * sizeof(float);
+static int launch_chain(K kernel, const char* name, int M, int RT, int KbA, int KbB, hipStream_t s, const Args& args,
+                        size_t extra_floats = 0) {
+    const size_t lds = ((size_t)RT * (KbA + KbB) * kFragFloats + kSplitScratchFloats + extra_floats) * sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "%s: chain needs %zu B of LDS (> %d)", name, lds, kMaxLds);
     if (lds > 64 * 1024 && allow_big_lds(kernel)) return -1;
     hipLaunchKernelGGL(kernel, dim3(cdiv(M, 16 * RT)), dim3(kThreads), lds, s, args, KbA, KbB);
@@ -130,13 +156,14 @@ static int launch_chain(K kernel, const char* name, int M, int RT, int KbA, int 
     return 0;
 }
 
-static int pick_rt(int M, int KbA, int KbB) {
+static int pick_rt(int M, int KbA, int KbB, size_t extra_per_rt = 0) {
     const int tiles = cdiv(M, 16);
     int rt = tiles >= 1024 ? 2 : 1;
     static const char* force = getenv("BD_MLP_RT");          // tuning experiments only
     if (force) rt = atoi(force) >= 2 && tiles >= 1024 ? 2 : 1;
     const size_t cap = force ? 80 * 1024 : 64 * 1024;         // 2 workgroups per CU
-    while (rt > 1 && ((size_t)rt * (KbA + KbB) * kFragFloats + kSplitScratchFloats) * sizeof(float) > cap) rt >>= 1;
+    while (rt > 1 && ((size_t)rt * ((KbA + KbB) * kFragFloats + extra_per_rt) + kSplitScratchFloats) * sizeof(float) > cap)
+        rt >>= 1;
     return rt;
 }
 
@@ -158,9 +185,16 @@ int bd_mlp_forward(const bd_mlp_fwd_args* a, void* stream) {
         kb = cdiv(L.K, 16) > kb ? cdiv(L.K, 16) : kb;
         k = L.N;
     }
-    const int rt = pick_rt(a->M, KbA, KbB);
-    if (rt == 2) return launch_chain(mlp_fwd_kernel<2, 2>, "bd_mlp_forward", a->M, 2, KbA, KbB, (hipStream_t)stream, *a);
-    return launch_chain(mlp_fwd_kernel<1, 4>, "bd_mlp_forward", a->M, 1, KbA, KbB, (hipStream_t)stream, *a);
+    size_t xs = 0;
+    if (a->gD > 0) {
+        BD_REQUIRE(a->gidx && a->gWT && a->gC > 0 && a->gC <= 256 && a->layer[0].N % 4 == 0,
+                   "bd_mlp_forward: one-hot segment needs gidx, gWT, 0 < gC <= 256 and N0 %% 4 == 0");
+        xs = (size_t)16 * a->layer[0].N;
+    }
+    const int rt = pick_rt(a->M, KbA, KbB, xs);
+    if (rt == 2)
+        return launch_chain(mlp_fwd_kernel<2, 2>, "bd_mlp_forward", a->M, 2, KbA, KbB, (hipStream_t)stream, *a, 2 * xs);
+    return launch_chain(mlp_fwd_kernel<1, 4>, "bd_mlp_forward", a->M, 1, KbA, KbB, (hipStream_t)stream, *a, xs);
 }
 
 int bd_mlp_backward(const bd_mlp_bwd_args* a, void* stream) {

@@ -23,6 +23,30 @@ namespace bd {
 __device__ __forceinline__ void state_gather(const CatGeo& g, const float* __restrict__ WT, int N, const int* __restrict__ sidx_l,
                                              const float* __restrict__ sw_l, const float* __restrict__ scale_l,
                                              float* __restrict__ out) {
+    if ((N & 3) == 0) {     // 16-byte loads, eight rows of the gather in flight per thread
+        const int N4 = N >> 2;
+        for (int i = bd_tid(); i < 16 * N4; i += blockDim.x) {
+            const int row = i / N4, c4 = i - row * N4;
+            const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(WT) + c4;
+            floatx4 s = floatx4{0.f, 0.f, 0.f, 0.f};
+            int f = 0;
+            for (; f + 8 <= g.D; f += 8) {
+                floatx4 t[8];
+                float w[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    w[j] = sw_l[row * g.D + f + j];
+                    t[j] = W4[(size_t)((f + j) * g.C + sidx_l[row * g.D + f + j]) * N4];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += w[j] * t[j];
+            }
+            for (; f < g.D; ++f) s += sw_l[row * g.D + f] * W4[(size_t)(f * g.C + sidx_l[row * g.D + f]) * N4];
+            if (scale_l) s *= scale_l[row];
+            reinterpret_cast<floatx4*>(out)[i] = s;
+        }
+        return;
+    }
     for (int i = bd_tid(); i < 16 * N; i += blockDim.x) {
         const int row = i / N, col = i - row * N;
         float s = 0.f;
@@ -83,10 +107,10 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
     float* xf = h_nxt + nh;
     float* qf = xf + nh;
     float* af = qf + nhd;
+    const CatFull gf(a.D, a.C);
     float* xs = af + Kb_a * kFragFloats;          // [16][Be] gathered W_es s~
-    float* lg = xs + 16 * a.Be;
-    float* qs = lg + g.image_floats();
-    float* sw_l = qs + g.image_floats();          // [16][D]
+    float* lg = xs + 16 * a.Be;                   // all S logits of the tile (swizzled image)
+    float* sw_l = lg + gf.image_floats();         // [16][D]
     float* mrow = sw_l + 16 * g.D;                // [16] nonterminal mask of the step
     int* sidx_l = reinterpret_cast<int*>(mrow + 16);   // [16][D]
 
@@ -163,8 +187,8 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
         });
         lds_barrier();
         // ---- E: posterior logits, sample ----
-        cat_head_forward(g, qf, Kb_hd, a.w_q2, a.b_q2, a.q_post + (tb + row0) * S, a.post_logits + (tb + row0) * S, rows_valid,
-                         lg, qs, sidx_l);
+        cat_head_forward_full(gf, qf, Kb_hd, a.w_q2, a.b_q2, a.q_post + (tb + row0) * S, a.post_logits + (tb + row0) * S,
+                              rows_valid, lg, sidx_l);
         for (int i = threadIdx.x; i < 16 * g.D; i += blockDim.x) {
             const int row = i / g.D;
             sw_l[i] = row < rows_valid ? 1.f : 0.f;
@@ -181,6 +205,9 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
 // column blocks nb = wave, wave + kWaves of an Hd-wide output) and writes the logit gradients to dlogit_row0 (global).
 //   g = [have_carry] (dE W_es^T-packed chunk) * scale_l[row]  +  dstate_row0 (global, row stride ld_ds)
 //   d logits = jacobian(g | logits)  +  dextra_row0 (global, row stride S; may be null)
+// Per 256-column chunk: (a) the carry's contraction, its epilogue adding the heads' gradient, beside the staging of the
+// chunk's logits -> barrier -> (b) one thread per (row, factor): softmax Jacobian, + direct logit gradient, out to HBM and
+// into the fragment tile of the chunk's K blocks -> barrier -> (c) MFMA accumulate (overlaps the next chunk's (a)).
 template <int NACC>
 __device__ __forceinline__ void cat_head_backward(const CatGeo& g, bool have_carry, const float* __restrict__ dE, int Kb_h,
                                                   const float* __restrict__ wt_embed_s, const float* __restrict__ scale_l,
@@ -196,7 +223,7 @@ __device__ __forceinline__ void cat_head_backward(const CatGeo& g, bool have_car
     for (int i = 0; i < NACC; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     for (int ch = 0; ch < g.NCH; ++ch) {
         const int n = g.cols(ch);
-        // (a) carry through the embed layer's state columns, logits staged beside it
+        // (a) g = carry through the embed layer's state columns + heads' gradient; logits staged beside it
         if (have_carry) {
             const Seg seg[1] = {{dE, wt_embed_s + (size_t)ch * (g.CW / 16) * Kb_h * kFragFloats, Kb_h}};
             tile_linear_g<1, 1>(seg, nullptr, n, [&](int, int nb, floatx4 a4) {
@@ -206,39 +233,41 @@ __device__ __forceinline__ void cat_head_backward(const CatGeo& g, bool have_car
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 4 * (lane >> 4) + r;
-                    pl[g.addr(row, fl, c)] = a4[r] * (scale_l ? scale_l[row] : 1.f);
+                    float v = 0.f;
+                    if (row < rows_valid)
+                        v = a4[r] * (scale_l ? scale_l[row] : 1.f) + dstate_row0[(size_t)row * ld_ds + ch * g.CW + colc];
+                    pl[g.addr(row, fl, c)] = v;
                 }
             });
         } else {
-            for (int i = tid; i < 16 * g.ld; i += blockDim.x) pl[i] = 0.f;
+            cat_stage(g, ch, dstate_row0, ld_ds, rows_valid, 0.f, pl);
         }
         cat_stage(g, ch, logits_row0, (size_t)g.S, rows_valid, 0.f, lgs);
         lds_barrier();
-        // (b1) + heads' gradient w.r.t. the state (coalesced)
-        for (int i = tid; i < 16 * g.CW; i += blockDim.x) {
-            const int row = i / g.CW, colc = i - row * g.CW;
-            if (colc < n && row < rows_valid) pl[g.addr_col(row, colc)] += dstate_row0[(size_t)row * ld_ds + ch * g.CW + colc];
-        }
-        lds_barrier();
-        // (b2) straight-through Jacobian per (row, factor), in place
+        // (b) straight-through Jacobian per (row, factor), + direct logit gradient (KL); out to HBM and into the fragment
+        //     tile of this chunk's K blocks (columns beyond the chunk's factors stay zero from the kernel's start)
         {
             const int nf = n / g.C;
             for (int i = tid; i < 16 * nf; i += blockDim.x) {
                 const int row = i / nf, fl = i - row * nf;
+                const size_t gi = (size_t)row * g.S + ch * g.CW + fl * g.C;
+                if (g.C == 32) {
+                    cat_jacobian_reg<32>(g, lgs, pl, row, fl, row < rows_valid, dextra_row0 ? dextra_row0 + gi : nullptr,
+                                         dlogit_row0 ? dlogit_row0 + gi : nullptr, dLf);
+                    continue;
+                }
                 cat_jacobian(g, lgs, pl, row, fl);
+                for (int c = 0; c < g.C; ++c) {
+                    float v = 0.f;
+                    if (row < rows_valid) {
+                        v = pl[g.addr(row, fl, c)] + (dextra_row0 ? dextra_row0[gi + c] : 0.f);
+                        if (dlogit_row0) dlogit_row0[gi + c] = v;
+                    }
+                    dLf[frag_idx(row, fl * g.C + c)] = v;
+                }
             }
-        }
-        lds_barrier();
-        // (b3) + direct logit gradient (KL); out to HBM and into the fragment tile of this chunk's K blocks
-        for (int i = tid; i < 16 * g.CW; i += blockDim.x) {
-            const int row = i / g.CW, colc = i - row * g.CW;
-            float v = 0.f;
-            if (colc < n && row < rows_valid) {
-                const size_t gi = (size_t)row * g.S + ch * g.CW + colc;
-                v = pl[g.addr_col(row, colc)] + (dextra_row0 ? dextra_row0[gi] : 0.f);
-                if (dlogit_row0) dlogit_row0[gi] = v;
-            }
-            dLf[frag_idx(row, colc)] = v;
+            const int npad = cdiv(n, 16) * 16 - n;       // columns of the last K block beyond the chunk's factors
+            for (int i = tid; i < 16 * npad; i += blockDim.x) dLf[frag_idx(i / npad, n + i % npad)] = 0.f;
         }
         lds_barrier();
         // (c) d hidden += d logits(chunk) * W2[chunk rows, :]   (wt2: packed transpose, out = Hd, in = S)
@@ -264,8 +293,10 @@ __device__ __forceinline__ void cat_head_backward(const CatGeo& g, bool have_car
                 }
             }
         }
-        lds_barrier();
+        // the next chunk's (a) writes pl / lgs (last read in (b), behind the barrier above); its (b) writes dLf, which
+        // (c) reads: that hazard is covered by the barrier after the next (a)
     }
+    lds_barrier();
 }
 
 // =====================================================================================================================
@@ -418,10 +449,10 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
     // one region, three tenants in disjoint phases: the actor head's split-K scratch, the entropy partial sums, the
     // prior head's logits / draws images (16-byte aligned: the host rounds the offsets)
     float* uni = reinterpret_cast<float*>(sidx_l + 16 * g.D);
+    const CatFull gf(a.D, a.C);
     float* scratch = uni;
     float* part = uni;                            // [kWaves][16][A][3]
-    float* lg = uni;
-    float* qs = uni + g.image_floats();
+    float* lg = uni;                              // all S prior logits of the tile (swizzled image)
 
     load_tile_concat<1>(h_cur, Kb_h, row0, a.N, a.start_feat, F, a.Be, nullptr, 0, 0);
     for (int i = threadIdx.x; i < 16 * g.D; i += blockDim.x) {
@@ -591,8 +622,8 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
             tile_linear_seg<kNI, 1>(segs, a.b_p1, a.Hd, hidden_epi(bufA, a.sv_p, tn, a.Hd));
         }
         lds_barrier();
-        cat_head_forward(g, bufA, Kb_hd, a.w_p2, a.b_p2, a.q_prior + (tn + row0) * S, a.prior_logits + (tn + row0) * S,
-                         rows_valid, lg, qs, sidx_l);
+        cat_head_forward_full(gf, bufA, Kb_hd, a.w_p2, a.b_p2, a.q_prior + (tn + row0) * S, a.prior_logits + (tn + row0) * S,
+                              rows_valid, lg, sidx_l);
         for (int i = tid; i < 16 * g.D; i += blockDim.x)
             if (i / g.D < rows_valid) a.sidx[(tn + row0) * g.D + i] = (unsigned char)sidx_l[i];
         write_onehot(g, sidx_l, sw_l, nullptr, a.feat + (tn + row0) * F + a.Be, (size_t)F, rows_valid);
@@ -830,7 +861,8 @@ int bd_observe_cat_forward(const bd_observe_cat_fwd_args* a, void* stream) {
     BD_REQUIRE(a->init_belief && a->init_state && a->actions && a->pre_emb && a->q_post, "bd_observe_cat_forward: missing inputs");
     BD_REQUIRE(a->feat && a->post_logits && a->sidx, "bd_observe_cat_forward: missing outputs");
     const int Kb_h = cdiv(a->Be, 16), Kb_a = cdiv(a->A, 16), Kb_hd = cdiv(a->Hd, 16);
-    const size_t lds = ((size_t)(3 * Kb_h + Kb_hd + Kb_a) * kFragFloats + 16 * a->Be + 2 * g.image_floats() + 2 * 16 * g.D + 16) *
+    const CatFull gf(a->D, a->C);
+    const size_t lds = ((size_t)(3 * Kb_h + Kb_hd + Kb_a) * kFragFloats + 16 * a->Be + gf.image_floats() + 2 * 16 * g.D + 16) *
                        sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_observe_cat_forward: needs %zu B of LDS", lds);
     if (lds > 64 * 1024 && allow_big_lds(observe_cat_fwd_kernel)) return -1;
@@ -870,7 +902,8 @@ int bd_imagine_cat_forward(const bd_imagine_cat_fwd_args* a, void* stream) {
     const int wmax = a->Be > a->Hd ? a->Be : a->Hd;
     size_t uni = (size_t)kSplitScratchFloats;
     if ((size_t)kWaves * 16 * a->A * 3 > uni) uni = (size_t)kWaves * 16 * a->A * 3;
-    if ((size_t)2 * g.image_floats() > uni) uni = (size_t)2 * g.image_floats();
+    const CatFull gf(a->D, a->C);
+    if ((size_t)gf.image_floats() > uni) uni = (size_t)gf.image_floats();
     const size_t fixed = (size_t)(3 * Kb_h + 2 * Kb_hd + Kb_a) * kFragFloats + 16 * wmax + 3 * 16 * a->A + 2 * 16 * g.D;
     const size_t lds = (fixed + uni) * sizeof(float);      // every term of `fixed` is a multiple of 16 floats
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_imagine_cat_forward: needs %zu B of LDS", lds);

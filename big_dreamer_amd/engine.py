@@ -459,6 +459,14 @@ class DreamerEngine:
             add("model", f"rew{l}", self.W("reward_model", f"model.{2 * l}.weight"), tr=True)
             add("critic", f"cri{l}", self.W("critic", f"model.{2 * l}.weight"), tr=(l > 0))
             add("critic_target", f"tgt{l}", self.W("critic_target", f"model.{2 * l}.weight"), tr=True)
+        if cat:     # heads on [h; one-hot s]: layer 0 = belief columns (packed) + a gather of the state columns (plain W^T)
+            heads = [("model", "reward_model", "rew"), ("critic", "critic", "cri"), ("critic_target", "critic_target", "tgt")]
+            if not self.pixel:
+                heads.append(("model", "observation_model", "obs"))
+            for grp, mod, prefix in heads:
+                W0 = self.W(mod, "model.0.weight")
+                add(grp, f"{prefix}0h", W0[:, :Be])
+                self._plain[f"{prefix}0sT"] = (torch.zeros(S, Hd, dtype=torch.float32, device=self.dev), W0[:, Be:], grp)
         Wa0 = self.W("actor", "model.0.weight")
         add("actor", "a0h", Wa0[:, :Be])
         if cat:
@@ -503,11 +511,15 @@ class DreamerEngine:
         return [(f"{prefix}{l}", self.W(mod, f"model.{2 * l}.bias"), sizes[l + 1], sizes[l],
                  cabi.ACT_ELU if l < DENSE_LAYERS else cabi.ACT_NONE) for l in range(DENSE_LAYERS + 1)]
 
-    def mlp_forward(self, M, in0, ld0, w0, layers, saves, out, ldo, in1=None, ld1=0, w1=0, raw_packs=False) -> None:
-        """layers: [(packed-weight key | packed tensor when raw_packs, bias, N, K, act)]."""
+    def mlp_forward(self, M, in0, ld0, w0, layers, saves, out, ldo, in1=None, ld1=0, w1=0, raw_packs=False,
+                    gather=None) -> None:
+        """layers: [(packed-weight key | packed tensor when raw_packs, bias, N, K, act)].
+        gather = (class indices [M x D] uint8, plain W0s^T [D*C x N0], D, C): a one-hot input segment of layer 0."""
         a = cabi.MlpFwdArgs()
         a.M, a.in0, a.ld0, a.w0 = M, ptr(in0), ld0, w0
         a.in1, a.ld1, a.w1 = ptr(in1), ld1, w1
+        if gather is not None:
+            a.gidx, a.gWT, a.gD, a.gC = ptr(gather[0]), ptr(gather[1]), gather[2], gather[3]
         a.n_layers = len(layers)
         for i, (key, bias, N, K, act) in enumerate(layers):
             a.layer[i] = cabi.Layer(ptr(key if raw_packs else self.pk[key]), ptr(bias), N, K, act,
@@ -788,7 +800,7 @@ class DreamerEngine:
         a.act_raw_init_std, a.act_min_std, a.act_mean_scale = ACT_RAW_INIT_STD, ACT_MIN_STD, ACT_MEAN_SCALE
         ifeat = self.buf(tag + feat_tag + "ifeat", Mi, d.Be + d.S)
         a.feat = ptr(ifeat)
-        a.sidx = ptr(self._buf_u8(tag + "isidx", Mi, d.cat_D))
+        a.sidx = ptr(self._buf_u8(tag + feat_tag + "isidx", Mi, d.cat_D))      # read by the critic update: double-buffered like ifeat
         a.prior_logits = ptr(self.buf(tag + "iprior_logits", Mi, d.S))
         ent, act = self.buf(tag + "entropy", Mi), self.buf(tag + "action", Mi, d.A)
         a.entropy, a.action = ptr(ent), ptr(act)
@@ -847,18 +859,27 @@ class DreamerEngine:
                                              ptr(pst), cabi.stream()))
         return pst, pm, ps
 
-    def dense_forward(self, mod: str, prefix: str, tag: str, x, ldx: int, M: int, out_width: int, rows=None):
-        """DenseModel forward with saved activations; `rows` = (r0, r1) runs that row range only (same buffers)."""
+    def dense_forward(self, mod: str, prefix: str, tag: str, x, ldx: int, M: int, out_width: int, rows=None, sidx=None):
+        """DenseModel forward with saved activations; `rows` = (r0, r1) runs that row range only (same buffers).
+        `sidx` (Categorical latents, x = [h; one-hot s]): the state's class indices [M x D] -- layer 0 then contracts the
+        belief columns only and gathers the state columns (bd_mlp_forward's one-hot segment).  The returned layer list is
+        the full-width one (the backward's d/d x is dense over all of [h; s])."""
         d = self.d
         layers = self._dense_spec(mod, prefix, ldx, out_width)
         acts = [self.buf(f"{tag}_act{l}", M, d.Hd) for l in range(DENSE_LAYERS)]
         out = self.buf(f"{tag}_out", M, out_width)
+        fl, w_in, gather = layers, ldx, None
+        if sidx is not None:
+            fl = [(f"{prefix}0h", layers[0][1], layers[0][2], d.Be, layers[0][4])] + layers[1:]
+            w_in, gather = d.Be, (sidx, self._plain[f"{prefix}0sT"][0], d.cat_D, d.cat_C)
         if rows is None:
-            self.mlp_forward(M, x, ldx, ldx, layers, acts + [None], out, out_width)
+            self.mlp_forward(M, x, ldx, w_in, fl, acts + [None], out, out_width, gather=gather)
         else:
             r0, r1 = rows
-            self.mlp_forward(r1 - r0, x.view(M, ldx)[r0:r1], ldx, ldx, layers, [t[r0:r1] for t in acts] + [None],
-                             out[r0:r1], out_width)
+            if gather is not None:
+                gather = (sidx[r0:r1],) + gather[1:]
+            self.mlp_forward(r1 - r0, x.view(M, ldx)[r0:r1], ldx, w_in, fl, [t[r0:r1] for t in acts] + [None],
+                             out[r0:r1], out_width, gather=gather)
         return out, acts, layers
 
     def imagine(self, start_feat, N: int, Hm: int, noise, save: bool = True, tag: str = "", feat_tag: str = "",
@@ -1148,8 +1169,10 @@ class DreamerEngine:
             elif self.pixel:
                 om_out, om_acts, om_layers = self.decode_pixels(feat).detach().view(N, d.O), None, None
             else:
-                om_out, om_acts, om_layers = self.dense_forward("observation_model", "obs", "om", feat, F, N, d.O)
-            rw_out, rw_acts, rw_layers = self.dense_forward("reward_model", "rew", "rw", feat, F, N, 1)
+                om_out, om_acts, om_layers = self.dense_forward("observation_model", "obs", "om", feat, F, N, d.O,
+                                                                sidx=self._buf[feat_tag + "sidx"] if cat else None)
+            rw_out, rw_acts, rw_layers = self.dense_forward("reward_model", "rew", "rw", feat, F, N, 1,
+                                                            sidx=self._buf[feat_tag + "sidx"] if cat else None)
 
         inv_rows = self.dp.mean_grad_scale(N)
         d_om, d_rw = self.buf("d_om_out", N, d.O), self.buf("d_rw_out", N, 1)
@@ -1346,10 +1369,11 @@ class DreamerEngine:
         ifeat, ent, act = self.imagine(feat, N, Hm, noise, feat_tag=ptag, split=self.img_split,
                                        start_sidx=self._buf[ptag + "sidx"] if d.categorical else None)
         r0 = self._img_split_rows
+        isidx = self._buf[ptag + "isidx"] if d.categorical else None
         with self.span("img_heads_fwd"):
             if not r0:
-                r_out, r_acts, r_layers = self.dense_forward("reward_model", "rew", "ir", ifeat, F, Mi, 1)
-                v_out, v_acts, v_layers = self.dense_forward("critic_target", "tgt", "iv", ifeat, F, Mi, 1)
+                r_out, r_acts, r_layers = self.dense_forward("reward_model", "rew", "ir", ifeat, F, Mi, 1, sidx=isidx)
+                v_out, v_acts, v_layers = self.dense_forward("critic_target", "tgt", "iv", ifeat, F, Mi, 1, sidx=isidx)
             else:       # rows of the first time segment on a helper stream, under the second segment of the rollout
                 with torch.cuda.stream(self._s_heads):
                     self._s_heads.wait_event(self._ev_img_half)
@@ -1368,13 +1392,13 @@ class DreamerEngine:
             ev_ret.record(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev_ret)
-                self._critic_phase(ifeat, returns, Mi, F, inv_mi, self.red_ws_side)
+                self._critic_phase(ifeat, returns, Mi, F, inv_mi, self.red_ws_side, isidx)
                 self._ev_cr_done[par] = torch.cuda.Event()
                 self._ev_cr_done[par].record(self._side)
         elif self.overlap_critic:    # fork: critic phase on the side stream, actor backward continues here
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
-                self._critic_phase(ifeat, returns, Mi, F, inv_mi, self.red_ws_side)
+                self._critic_phase(ifeat, returns, Mi, F, inv_mi, self.red_ws_side, isidx)
         d_r, d_v = self.buf("d_ir_out", Mi), self.buf("d_iv_out", Mi)
         cabi.check(lib.bd_lambda_return_backward(None, -inv_mi, Hm, N, hp["discount"], hp["disclam"], ptr(d_r), ptr(d_v), st))
         difeat = self.buf("difeat", Mi, F)
@@ -1428,18 +1452,18 @@ class DreamerEngine:
         if par is not None:
             pass
         elif not self.overlap_critic:
-            self._critic_phase(ifeat, returns, Mi, F, inv_mi, red_ws)
+            self._critic_phase(ifeat, returns, Mi, F, inv_mi, red_ws, isidx)
         else:
             torch.cuda.current_stream().wait_stream(self._side)     # join before the next step reuses ifeat / returns
         self._counts = dict(N=N, Mi=Mi, S=(d.cat_D if d.categorical else d.S), sum_form=sum_form)
 
-    def _critic_phase(self, ifeat, returns, Mi: int, F: int, inv_mi: float, red_ws: torch.Tensor) -> None:
+    def _critic_phase(self, ifeat, returns, Mi: int, F: int, inv_mi: float, red_ws: torch.Tensor, isidx=None) -> None:
         """Critic update (src/dreamer.py:370-391) on the current stream: forward on the detached imagined features,
         Normal(v, 1) NLL against the detached returns, dgrad chain, grouped weight gradients, clip + Adam, re-pack."""
         d, hp = self.d, self.hp
         st, sc = cabi.stream(), ptr(self.scalars)
         with self.span("critic_fwd_bwd"):
-            c_out, c_acts, c_layers = self.dense_forward("critic", "cri", "ic", ifeat, F, Mi, 1)
+            c_out, c_acts, c_layers = self.dense_forward("critic", "cri", "ic", ifeat, F, Mi, 1, sidx=isidx)
             d_c = self.buf("d_ic_out", Mi, 1)
             cabi.check(lib.bd_normal_nll(ptr(c_out), 1, ptr(returns), 1, Mi, 1, inv_mi, ptr(d_c), 1, sc, SLOT_VAL, ptr(red_ws), st))
             c_dpre = [self.buf(f"ic_dpre{l}", Mi, d.Hd) for l in range(DENSE_LAYERS)] + [d_c]

@@ -68,6 +68,11 @@ typedef struct {
     int n_layers;
     bd_layer layer[BD_MAX_LAYERS];
     float* out; int ldo;            /* last layer's output [M x N_last]                            */
+    /* Optional one-hot (Categorical) input segment BESIDE [in0 | in1]: gD factors of gC classes given as class indices
+     * gidx [M x gD] (uint8).  Layer 0 then computes  act(W0 [in0 | in1] + sum_f gWT[f*gC + gidx[m][f]] + b)  with
+     * gWT the plain row-major TRANSPOSE [gD*gC x N0] of the layer's one-hot columns: a gather of gD rows instead of a
+     * K = gD*gC contraction (DenseModel(belief, state) on [h; one-hot s]).  gD = 0: absent. */
+    const unsigned char* gidx; const float* gWT; int gD, gC;
 } bd_mlp_fwd_args;
 int bd_mlp_forward(const bd_mlp_fwd_args* a, void* stream);
 
