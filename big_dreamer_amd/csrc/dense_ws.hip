@@ -11,6 +11,7 @@
 // no weight traffic; activations make one HBM round trip per layer.
 #include "bd_device.h"
 #include "bd_host.h"
+#include <stdlib.h>
 
 namespace bd {
 
@@ -144,6 +145,48 @@ __global__ __launch_bounds__(kWsThreads) void mfma_probe_kernel(int iters, float
     if (s == 12345.678f) out[0] = s;        // keeps the chains alive; never true in practice
 }
 
+// Diagnostic variants of the MFMA loop: (1) operands change with every instruction (16 A registers x 16 B registers, as a
+// real contraction has them) instead of one constant pair; (2) additionally the A operands come from LDS (ds_read_b128 per
+// four MFMAs, prefetched one group ahead).
+template <int VARIANT>
+__global__ __launch_bounds__(kWsThreads) void mfma_probe2_kernel(int iters, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float lds[16 * 256];
+    for (int i = threadIdx.x; i < 16 * 256; i += blockDim.x) lds[i] = (float)(i & 15) * 0.0625f;
+    __syncthreads();
+    float a[16], b[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        a[i] = (float)((threadIdx.x + i) & 7) * 0.125f;
+        b[i] = (float)((threadIdx.x + 3 * i) & 3) * 0.25f;
+    }
+    floatx4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const floatx4* __restrict__ X = reinterpret_cast<const floatx4*>(lds) + (threadIdx.x & 63);
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (VARIANT == 1) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = mfma16(a[(u * 4 + i) & 15], b[(u * 4 + i + 5) & 15], acc[i]);
+            }
+        } else {
+            floatx4 x = X[0];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const floatx4 nx = X[((u + 1) & 15) * 64];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = mfma16(x[i], b[(u * 4 + i) & 15], acc[i]);
+                x = nx;
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678f) out[0] = s;
+}
+
 template <int KB>
 static int launch_ws(const WsArgs& a, hipStream_t s) {
     const int ntiles = (a.M + 15) / 16;
@@ -183,7 +226,13 @@ int bd_dense_ws(const float* in, int ldi, const float* w_packed, const float* bi
 /* diagnostic: `iters` x 32 MFMAs per wave on 16 waves x `blocks` workgroups; flops = blocks * 16 * iters * 32 * 2048 */
 int bd_mfma_probe(int blocks, int iters, float* out, void* stream) {
     BD_REQUIRE(blocks > 0 && iters > 0 && out, "bd_mfma_probe: bad arguments");
-    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(kWsThreads), 0, (hipStream_t)stream, iters, out);
+    static const char* th = getenv("BD_PROBE_THREADS");       // diagnostic: waves per workgroup = threads / 64 (default 16)
+    const int threads = th ? atoi(th) : kWsThreads;
+    static const char* vr = getenv("BD_PROBE_VARIANT");
+    const int variant = vr ? atoi(vr) : 0;
+    if (variant == 1) hipLaunchKernelGGL(mfma_probe2_kernel<1>, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, iters, out);
+    else if (variant == 2) hipLaunchKernelGGL(mfma_probe2_kernel<2>, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, iters, out);
+    else hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, iters, out);
     BD_CHECK_LAUNCH("bd_mfma_probe");
     return 0;
 }

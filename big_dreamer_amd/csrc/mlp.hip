@@ -7,6 +7,12 @@
 
 namespace bd {
 
+// weight-stationary form for tall chains (chain_ws.hip)
+bool chain_ws_forward_ok(const bd_mlp_fwd_args* a);
+int chain_ws_forward(const bd_mlp_fwd_args* a, hipStream_t s);
+bool chain_ws_backward_ok(const bd_mlp_bwd_args* a);
+int chain_ws_backward(const bd_mlp_bwd_args* a, hipStream_t s);
+
 // ---- forward --------------------------------------------------------------------------------------
 template <int RT, int NI>
 __global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, int KbA, int KbB) {
@@ -185,6 +191,7 @@ int bd_mlp_forward(const bd_mlp_fwd_args* a, void* stream) {
         kb = cdiv(L.K, 16) > kb ? cdiv(L.K, 16) : kb;
         k = L.N;
     }
+    if (chain_ws_forward_ok(a)) return chain_ws_forward(a, (hipStream_t)stream);
     size_t xs = 0;
     if (a->gD > 0) {
         BD_REQUIRE(a->gidx && a->gWT && a->gC > 0 && a->gC <= 256 && a->layer[0].N % 4 == 0,
@@ -214,6 +221,7 @@ int bd_mlp_backward(const bd_mlp_bwd_args* a, void* stream) {
         kb = cdiv(L.N, 16) > kb ? cdiv(L.N, 16) : kb;
     }
     if (want_din) BD_REQUIRE(a->w0 + a->w1 == a->layer[0].K, "bd_mlp_backward: din widths != K of layer 0");
+    if (chain_ws_backward_ok(a)) return chain_ws_backward(a, (hipStream_t)stream);
     const int rt = pick_rt(a->M, KbA, KbB);
     if (rt == 2) return launch_chain(mlp_bwd_kernel<2, 2>, "bd_mlp_backward", a->M, 2, KbA, KbB, (hipStream_t)stream, *a);
     return launch_chain(mlp_bwd_kernel<1, 4>, "bd_mlp_backward", a->M, 1, KbA, KbB, (hipStream_t)stream, *a);

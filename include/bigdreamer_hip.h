@@ -95,6 +95,11 @@ typedef struct {
     int accumulate;                 /* 1: din += , 0: din =                                         */
 } bd_mlp_bwd_args;
 int bd_mlp_backward(const bd_mlp_bwd_args* a, void* stream);
+/* Tall chains (M >= 16384 rows: the heads over the imagined trajectories) also have a weight-stationary persistent form
+ * (csrc/chain_ws.hip) behind the two entry points above; same arguments, same results.  mode 0: per-tile form (the
+ * default), 1: weight-stationary forward, 2: weight-stationary forward and backward, -1: as the environment says
+ * (BD_CHAIN_WS=1|2; unset = off: measured no faster inside the three-stream step). */
+int bd_chain_ws_set_mode(int mode);
 
 /* dW[N x K] (+)= dpre^T[N x M] * act[M x K],  db[N] (+)= column sums of dpre (db may be NULL).
  * Deterministic split-M (slabs in `ws`, then a fixed-order reduction); accumulate=1 adds to dW/db;
