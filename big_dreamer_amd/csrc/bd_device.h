@@ -193,6 +193,32 @@ __device__ __forceinline__ void pipelined_k(int Kb, LoadF&& load, MmaF&& mma) {
         if (i < nt) mma(T[i]);
 }
 
+// Three register sets, one K block each: block kb is consumed while kb+1 and kb+2 are in flight (prefetch distance two
+// stages).  For the GRU stages (eight to ten float4 per stage, 24 MFMAs = 768 cycles of matrix-pipe time) the two-set form
+// covers one stage of latency, less than a loaded L2 round trip: with two waves per SIMD the pipe sits at ~65 % in that
+// phase (s_memtime stamps: 62k cycles for a 40k-cycle contraction); D = 2 sets of two blocks spill.  Experiment only:
+// the extra live registers cost more than the deeper prefetch buys (see BD_GRU_PIPE3 below).
+template <class LoadF, class MmaF>
+__device__ __forceinline__ void pipelined_k3(int Kb, LoadF&& load, MmaF&& mma) {
+    using Frag = decltype(load(0));
+    Frag A = load(0), B = A, C = A;
+    if (Kb > 1) B = load(1);
+    int kb = 0;
+    for (; kb + 3 <= Kb; kb += 3) {
+        C = load(kb + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(A);
+        if (kb + 3 < Kb) A = load(kb + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(B);
+        if (kb + 4 < Kb) B = load(kb + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(C);
+    }
+    if (kb < Kb) mma(A);
+    if (kb + 1 < Kb) mma(B);
+}
+
 // ---- the core contraction: out[16*RT x N] = sum_s X_s[16*RT x K_s] * W_s^T + bias -----------------------
 // The reference's concatenated inputs (torch.cat([belief, state]), cat(state, action)) are kept as separate
 // LDS fragment tiles ("segments") with separately packed weight column blocks.
@@ -618,6 +644,17 @@ __device__ __forceinline__ void tile_dual_head_elem(const Seg2 (&seg)[NSEG], con
     }
 }
 
+// (-DBD_GRU_PIPE3=1 selects the three-set pipeline for the GRU stages: measured SLOWER on MI355X -- imagination forward
+// 0.93 vs 0.88 ms alone, step 3.54 vs 3.46 ms -- so the two-set form stays)
+#ifndef BD_GRU_PIPE3
+#define BD_GRU_PIPE3 0
+#endif
+#if BD_GRU_PIPE3
+#define BD_GRU_PIPE pipelined_k3
+#else
+#define BD_GRU_PIPE pipelined_k<1>
+#endif
+
 // ---- GRU cell (nn.GRUCell, src/models.py:149,252): four accumulators per output column block ----------
 //   R  = W_ir x + W_hr h + b_ir + b_hr      Z  = W_iz x + W_hz h + b_iz + b_hz
 //   NI = W_in x + b_in                      NH = W_hn h + b_hn
@@ -654,7 +691,7 @@ __device__ __forceinline__ void gru_tile(const float* __restrict__ X, const floa
         const floatx4* __restrict__ Whr = reinterpret_cast<const floatx4*>(w.w_hr) + off;
         const floatx4* __restrict__ Whz = reinterpret_cast<const floatx4*>(w.w_hz) + off;
         const floatx4* __restrict__ Whn = reinterpret_cast<const floatx4*>(w.w_hn) + off;
-        pipelined_k<1>(
+        BD_GRU_PIPE(
             Kb,
             [&](int kb) {
                 return GruFrag{X4[kb * 64], H4[kb * 64], Wir[kb * 64], Wiz[kb * 64], Win[kb * 64],
@@ -705,7 +742,7 @@ __device__ __forceinline__ void gru_tile_bwd(const float* __restrict__ dR, const
         const floatx4* __restrict__ Whr = reinterpret_cast<const floatx4*>(w.wt_hr) + off;
         const floatx4* __restrict__ Whz = reinterpret_cast<const floatx4*>(w.wt_hz) + off;
         const floatx4* __restrict__ Whn = reinterpret_cast<const floatx4*>(w.wt_hn) + off;
-        pipelined_k<1>(
+        BD_GRU_PIPE(
             Kb,
             [&](int kb) {
                 return GruBwdFrag{R4[kb * 64], Z4[kb * 64], I4[kb * 64], H4[kb * 64], Wir[kb * 64], Wiz[kb * 64],

@@ -1,5 +1,8 @@
 """GPU tests of the hand-written conv gather-GEMMs (csrc/conv.hip) against torch's F.conv2d / F.conv_transpose2d on the
-layer shapes of the reference's CnnImageEncoder / ObservationModel (src/models.py:319-362, 527-564)."""
+layer shapes of the reference's CnnImageEncoder / ObservationModel (src/models.py:319-362, 527-564).
+The reference values are computed by torch ON THE CPU in fp32 (the ops the reference's disable_cuda=True path runs), not
+by MIOpen on the device: inputs are generated on the device, copied to the host for the reference, and the results
+compared there."""
 import numpy as np
 import pytest
 import torch
@@ -9,6 +12,10 @@ pytestmark = pytest.mark.gpu
 
 ENC = [(3, 32, 4, 64), (32, 64, 4, 31), (64, 128, 4, 14), (128, 256, 4, 6)]        # (Cin, Cout, k, input size)
 DEC = [(128, 64, 5, 5), (64, 32, 6, 13), (32, 3, 6, 30)]                           # ConvT after the 1x1 -> 5x5 layer
+
+
+def _cpu(*ts):
+    return [None if t is None else t.detach().cpu() for t in ts]
 
 
 def _close(got, want, tol=2e-5):
@@ -25,7 +32,7 @@ def test_pattern_f_matches_conv2d_and_layout_roundtrip(Cin, Cout, k, size):
     x = torch.randn(imgs, Cin, size, size, device="cuda", generator=g)
     w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) * 0.1
     b = torch.randn(Cout, device="cuda", generator=g)
-    want = Fnn.elu(Fnn.conv2d(x, w, b, stride=2))
+    want = Fnn.elu(Fnn.conv2d(*_cpu(x, w, b), stride=2))
     xs = conv.to_nhwc(x)
     assert torch.equal(conv.to_nchw(xs), x)
     stored = w.permute(0, 2, 3, 1).contiguous()                       # (co, ky, kx, ci)
@@ -46,7 +53,7 @@ def test_pattern_t_matches_conv_transpose2d(Cin, Cout, k, size):
     x = torch.randn(imgs, Cin, size, size, device="cuda", generator=g)
     w = torch.randn(Cin, Cout, k, k, device="cuda", generator=g) * 0.1
     b = torch.randn(Cout, device="cuda", generator=g)
-    want = Fnn.conv_transpose2d(x, w, b, stride=2)
+    want = Fnn.conv_transpose2d(*_cpu(x, w, b), stride=2)
     stored = w.permute(0, 2, 3, 1).contiguous()                       # (ci, ky, kx, co)
     packs = [torch.zeros(n, device="cuda") for n in conv.class_pack_floats(Cin, Cout, k)]
     conv.pack_classes(stored, packs, Cin, Cout, k)
@@ -68,11 +75,12 @@ def test_conv2d_dgrad_is_pattern_t_and_convT_dgrad_is_pattern_f(Cin, Cout, k, si
     from big_dreamer_amd import _cabi as cabi, conv
     g = torch.Generator(device="cuda").manual_seed(3)
     imgs = 4
-    x = torch.randn(imgs, Cin, size, size, device="cuda", generator=g, requires_grad=True)
+    x = torch.randn(imgs, Cin, size, size, device="cuda", generator=g)
     w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) * 0.1
-    y = Fnn.conv2d(x, w, None, stride=2)
-    gy = torch.randn_like(y)
-    (gx,) = torch.autograd.grad(y, x, gy)
+    OHc = (size - k) // 2 + 1
+    gy = torch.randn(imgs, Cout, OHc, OHc, device="cuda", generator=g)
+    xc = x.cpu().requires_grad_(True)
+    (gx,) = torch.autograd.grad(Fnn.conv2d(xc, w.cpu(), None, stride=2), xc, gy.cpu())
     stored = w.permute(0, 2, 3, 1).contiguous()                       # (co, ky, kx, ci): outer = co = K side of the dgrad
     packs = [torch.zeros(n, device="cuda") for n in conv.class_pack_floats(Cout, Cin, k)]
     conv.pack_classes(stored, packs, Cout, Cin, k)
@@ -87,10 +95,11 @@ def test_conv2d_dgrad_is_pattern_t_and_convT_dgrad_is_pattern_f(Cin, Cout, k, si
     conv.pattern_t_fused(gys, out2, fused, None, imgs, OH, OH, Cout, k, Cin, size, size, cabi.ACT_NONE)
     _close(conv.to_nchw(out2), gx)
     # transposed convolution with the same tensor as its (ci=Cout, co=Cin) weight: dgrad = strided conv of the gradient
-    xt = torch.randn(imgs, Cout, OH, OH, device="cuda", generator=g, requires_grad=True)
-    yt = Fnn.conv_transpose2d(xt, w, None, stride=2)                  # w viewed as (ci=Cout, co=Cin, k, k)
-    gyt = torch.randn_like(yt)
-    (gxt,) = torch.autograd.grad(yt, xt, gyt)
+    xt = torch.randn(imgs, Cout, OH, OH, device="cuda", generator=g)
+    HTc = 2 * (OH - 1) + k
+    gyt = torch.randn(imgs, Cin, HTc, HTc, device="cuda", generator=g)
+    xtc = xt.cpu().requires_grad_(True)
+    (gxt,) = torch.autograd.grad(Fnn.conv_transpose2d(xtc, w.cpu(), None, stride=2), xtc, gyt.cpu())   # w as (ci=Cout, co=Cin, k, k)
     Kt = k * k * Cin
     wp = torch.zeros(cabi.packed_floats(Cout, Kt), device="cuda")
     conv.pack_matrix(stored.view(Cout, Kt), wp, Cout, Kt)             # stored = (ci_T, ky, kx, co_T) for the transposed conv
@@ -110,7 +119,7 @@ def test_gathered_wgrad_matches_conv_weight_gradients(Cin, Cout, k, size):
     x = torch.randn(imgs, Cin, size, size, device="cuda", generator=g)
     w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) * 0.1
     gy = torch.randn(imgs, Cout, OH, OH, device="cuda", generator=g)
-    _, gw_ref, gb_ref = torch.ops.aten.convolution_backward(gy, x, w, [Cout], [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
+    _, gw_ref, gb_ref = torch.ops.aten.convolution_backward(*_cpu(gy, x, w), [Cout], [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
                                                             [False, True, True])
     dW = torch.zeros(Cout, k, k, Cin, device="cuda")
     db = torch.zeros(Cout, device="cuda")
@@ -123,7 +132,7 @@ def test_gathered_wgrad_matches_conv_weight_gradients(Cin, Cout, k, size):
     HT = conv.convT_out(OH, k)
     xt = torch.randn(imgs, Cout, OH, OH, device="cuda", generator=g)
     gyt = torch.randn(imgs, Cin, HT, HT, device="cuda", generator=g)
-    _, gwt_ref, _ = torch.ops.aten.convolution_backward(gyt, xt, w, None, [2, 2], [0, 0], [1, 1], True, [0, 0], 1,
+    _, gwt_ref, _ = torch.ops.aten.convolution_backward(*_cpu(gyt, xt, w), None, [2, 2], [0, 0], [1, 1], True, [0, 0], 1,
                                                         [False, True, False])
     dWt = torch.zeros(Cout, k, k, Cin, device="cuda")
     xts = conv.to_nhwc(xt).view(imgs * OH * OH, Cout)

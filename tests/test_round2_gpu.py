@@ -229,3 +229,16 @@ def test_weight_stationary_chain_matches_the_per_tile_chain():
     for i, (x, y) in enumerate(zip(keep[0], keep[2])):
         scale = float(x.abs().max())
         assert float((x - y).abs().max()) <= 2e-6 * max(1.0, scale), (i, float((x - y).abs().max()), scale)
+
+
+def test_exact_math_build():
+    """The -DBD_EXACT_MATH build (libm-grade ELU / sigmoid / tanh / softplus in the epilogues; `make exact`, built by
+    __graft_entry__.build()) loaded through BD_LIB in a fresh process: two train steps of the `small` case against the
+    oracle.  With exact activations the beliefs agree to summation-order noise (1e-6), weights after Adam to 2e-6."""
+    lib = os.path.join(ROOT, "big_dreamer_amd", "libbigdreamer_hip_exact.so")
+    assert os.path.exists(lib), "libbigdreamer_hip_exact.so missing: run __graft_entry__.build() (make exact)"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "exact_worker.py")], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT, env=dict(os.environ, BD_LIB=lib))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("EXACT_RESULT ")][-1][len("EXACT_RESULT "):])
+    assert res["belief"] < 2e-6 and res["weight"] < 2e-6 and res["log"] < 1e-5, res
