@@ -146,5 +146,33 @@ if os.path.exists(os.path.join(src, "pixel_bench.json")):
     readme.write(f"`wgrad_wide_kernel` by position in the step (kernel trace, us): {[round(m, 1) for m in means]} -> the decoder's "
                  f"grouped launch is position {dec}.\n\n")
     table(readme, ptraffic)
+# ------------------------------------------------------------------------------------------------ categorical config
+if os.path.exists(os.path.join(src, "cat_bench.json")):
+    cb = json.loads(open(os.path.join(src, "cat_bench.json")).read().strip().splitlines()[-1])
+    cstats = glob.glob(os.path.join(src, "cat_stats", "*", "*_kernel_stats.csv"))[0]
+    shutil.copy(cstats, os.path.join(dst, f"{tag}_cat_kernel_stats.csv"))
+    names = {"imagine_fwd": "imagine_cat_fwd_kernel", "imagine_bwd": "imagine_cat_bwd_kernel",
+             "observe_fwd": "observe_cat_fwd_kernel", "observe_bwd": "observe_cat_bwd_kernel",
+             "mlp_fwd (all launches, mean)": "mlp_fwd_kernel", "mlp_bwd (all launches, mean)": "mlp_bwd_kernel",
+             "wgrad_wide (all launches, mean)": "wgrad_wide_kernel"}
+    ctraffic = traffic_of(pmc("cat_pmc_fetch"), pmc("cat_pmc_write"), pmc("cat_pmc_sq"), names)
+    json.dump(ctraffic, open(os.path.join(dst, f"{tag}_cat_traffic.json"), "w"), indent=1)
+    dom = cb["roofline"]["kernel"]
+    if dom in ctraffic:
+        cb["roofline"]["traffic"] = ctraffic[dom]["hbm_bytes_per_launch"]
+        cb["roofline"]["traffic_source"] = f"{tag}_cat_traffic.json"
+    json.dump(cb, open(os.path.join(dst, f"{tag}_cat_bench.json"), "w"))
+    crow = list(csv.DictReader(open(cstats)))
+    readme.write("\n## BASELINE configs[4] per GPU (`python bench.py --categorical pixel`): dreamerV2 32x32 Categorical latents, "
+                 "64x64 pixels, A=17, batch 100 (= 800 / 8)\n\n")
+    readme.write(f"Bench line (un-profiled, {cb['steps']} steps): **{cb['value']:.0f} {cb['unit']}**, {cb['ms_per_step']:.3f} ms/step")
+    if os.path.exists(os.path.join(src, "cat_state_bench.json")):
+        sb = json.loads(open(os.path.join(src, "cat_state_bench.json")).read().strip().splitlines()[-1])
+        json.dump(sb, open(os.path.join(dst, f"{tag}_cat_state_bench.json"), "w"))
+        readme.write(f"; the same latents on state observations (`--categorical state`): {sb['value']:.0f}, {sb['ms_per_step']:.3f} ms/step")
+    readme.write(".\n\n")
+    stats_table(readme, crow, 16)
+    readme.write("\nHIP-event averages inside bench.py (ms): " + json.dumps(cb["kernel_ms"]) + "\n\n")
+    table(readme, ctraffic)
 readme.close()
 print(open(os.path.join(dst, f"{tag}_README.md")).read())
