@@ -95,7 +95,10 @@ def cpu_baseline(d, budget_s=15.0, max_steps=8):   # (pixel: ~8 s per step -> 1-
     torch.set_num_threads(cores)
     log(f"cpu_baseline: os.cpu_count()={os.cpu_count()} usable={usable_cpus()} -> {cores} threads")
     P, batch, noise = synth.make_params(d, 0), synth.make_batch(d, 0), synth.make_noise(d, 0)
-    od = O.OracleDreamer(P, dict(planning_horizon=d.H))
+    hp = dict(planning_horizon=d.H)
+    if d.categorical:
+        hp["categorical"] = (d.cat_D, d.cat_C)
+    od = O.OracleDreamer(P, hp)
     t0 = time.perf_counter()
     od.train_step(batch, noise, keep=False)            # warm-up
     log(f"cpu_baseline: warm-up step {time.perf_counter() - t0:.2f} s")
@@ -106,7 +109,7 @@ def cpu_baseline(d, budget_s=15.0, max_steps=8):   # (pixel: ~8 s per step -> 1-
     dt = time.perf_counter() - t0
     return {"value": d.transitions_per_step * steps / dt, "unit": "latent transitions/s",
             "cores": cores, "kind": "port",
-            "sample": f"{steps} full train_steps (batch=50 chunk=50 H=15) after 1 warm-up, torch fp32 CPU, "
+            "sample": f"{steps} full train_steps (batch={d.B} chunk={d.L} H={d.H}) after 1 warm-up, torch fp32 CPU, "
                       f"{dt / steps * 1e3:.0f} ms/step"}
 
 
