@@ -122,6 +122,19 @@ def decoder_wgrad_flops(d):
     return per_img * d.N
 
 
+def pixel_roofline(d, kt):
+    """Roofline record of the pixel step's dominant kernel: the decoder's grouped weight-gradient GEMM (24 % of the GPU
+    time of configs[2], profiles/*_pixel_kernel_stats.csv), bracketed alone by HIP events (span wgrad_gemm_model_early)."""
+    dom = "wgrad_gemm_model_early"
+    fl = decoder_wgrad_flops(d)
+    ach = fl / (kt[dom][0] * 1e-3) / 1e12
+    traffic, src = measured_traffic("wgrad_decoder", "pixel")
+    return {"bound": "mfma", "kernel": "wgrad_wide_kernel (decoder conv weight gradients, one grouped launch)",
+            "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+            "traffic": traffic, "traffic_source": src, "avg_launch_ms": kt[dom][0], "launches_timed": kt[dom][1],
+            "algorithmic_flop_per_launch": fl}
+
+
 def run_workload(d, pixel, args, rank, world, dev, dist_on, steps, warmup, timers=True):
     """Build engine + HBM-resident synthetic replay for `d`, run warmup + exactly `steps` timed train steps between
     barrier + synchronise fences.  Returns (dt max over ranks, HIP-event spans, last logs, engine)."""
@@ -303,11 +316,12 @@ def main():
                        ("BASELINE.json configs[1]: state-obs Dreamer train_step, belief=200 state=30 "
                         "hidden=200 embedding=1024 action=1 obs=3, batch=50/GPU chunk=50 H=15"),
                        "global_batch": d.B * world, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "avg_launch_ms": kt[dom][0], "launches_timed": kt[dom][1],
-                         "algorithmic_flop_per_launch": flops[dom]},
+            "roofline": (pixel_roofline(d, kt) if (args.pixel and not args.categorical and "wgrad_gemm_model_early" in kt) else
+                         {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                          "traffic_source": traffic_src,
+                          "avg_launch_ms": kt[dom][0], "launches_timed": kt[dom][1],
+                          "algorithmic_flop_per_launch": flops[dom]}),
             "hbm_roofline_whole_step": {"achieved": step_bytes / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBPS,
                                         "unit": "GB/s", "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS,
                                         "algorithmic_bytes_per_step": step_bytes},
@@ -331,20 +345,12 @@ def main():
         d3 = synth.CONFIG3
         psteps = max(5, min(20, args.steps))
         pdt, pkt, plogs, peng = run_workload(d3, True, args, rank, world, dev, False, psteps, 3)
-        pdom = "wgrad_gemm_model_early"
-        pfl = decoder_wgrad_flops(d3)
-        pach = pfl / (pkt[pdom][0] * 1e-3) / 1e12
-        ptraffic, psrc = measured_traffic("wgrad_decoder", "pixel")
         out["secondary"] = {
             "workload": "BASELINE.json configs[2]: 64x64 pixel-obs Dreamer train_step, conv encoder/decoder on this "
                         "library's gather-GEMM kernels, action=17, batch=50 chunk=50 H=15",
             "value": d3.transitions_per_step * psteps / pdt, "unit": "latent transitions/s",
             "ms_per_step": pdt / psteps * 1e3, "steps": psteps, "warmup": 3,
-            "roofline": {"bound": "mfma", "kernel": "wgrad_wide_kernel (decoder conv weight gradients, one grouped launch)",
-                         "achieved": pach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": pach / FP32_MFMA_PEAK_TFLOPS, "traffic": ptraffic, "traffic_source": psrc,
-                         "avg_launch_ms": pkt[pdom][0], "launches_timed": pkt[pdom][1],
-                         "algorithmic_flop_per_launch": pfl},
+            "roofline": pixel_roofline(d3, pkt),
             "kernel_ms": {k: round(v[0], 4) for k, v in pkt.items()},
             "losses": {k: round(v, 5) for k, v in plogs.items()},
         }
