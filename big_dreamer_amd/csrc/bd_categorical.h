@@ -44,14 +44,43 @@ struct CatGeo {
 };
 
 // Coalesced copy of the chunk's columns of 16 global rows (row stride ld_g) into a swizzled image; rows >= rows_valid
-// and columns >= S read `fill`.
+// and columns >= S read `fill`.  All of a thread's loads are issued before its first LDS write (16-byte loads where the
+// layout allows): written as load-store pairs the loop paid one global round trip per element.
 __device__ __forceinline__ void cat_stage(const CatGeo& g, int ch, const float* __restrict__ src, size_t ld_g, int rows_valid,
                                           float fill, float* __restrict__ img) {
     const int n = g.cols(ch);
+    const float* __restrict__ base = src + ch * g.CW;
+    if ((n & 3) == 0 && (ld_g & 3) == 0 && (g.C & 3) == 0 && (((uintptr_t)base) & 15) == 0) {
+        const int n4 = n >> 2, total = 16 * n4;
+        constexpr int NIT = 4;
+        for (int i0 = bd_tid(); i0 < total; i0 += NIT * blockDim.x) {
+            floatx4 v[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = i0 + it * blockDim.x;
+                v[it] = floatx4{fill, fill, fill, fill};
+                if (i < total) {
+                    const int row = i / n4, c4 = i - row * n4;
+                    if (row < rows_valid) v[it] = *reinterpret_cast<const floatx4*>(base + (size_t)row * ld_g + 4 * c4);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = i0 + it * blockDim.x;
+                if (i < total) {
+                    const int row = i / n4, colc = 4 * (i - row * n4);
+                    const int fl = colc / g.C, c = colc - fl * g.C;      // the four classes share a factor (C % 4 == 0)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) img[g.addr(row, fl, c + j)] = v[it][j];
+                }
+            }
+        }
+        return;
+    }
     for (int i = bd_tid(); i < 16 * g.CW; i += blockDim.x) {
         const int row = i / g.CW, colc = i - row * g.CW;
         if (colc >= n) continue;
-        img[g.addr_col(row, colc)] = row < rows_valid ? src[(size_t)row * ld_g + ch * g.CW + colc] : fill;
+        img[g.addr_col(row, colc)] = row < rows_valid ? base[(size_t)row * ld_g + colc] : fill;
     }
 }
 
@@ -157,6 +186,66 @@ __device__ __forceinline__ void cat_jacobian_reg(const CatGeo& g, const float* _
     }
 }
 
+// C == 32, FOUR lanes per (row, factor), eight classes each: every thread of the workgroup works (16 rows x 8 factors of a
+// 256-column chunk x 4 = 512), the three per-factor reductions (max, sum of exponentials, probs . g) are two quad
+// shuffles each, the softmax needs ONE hardware exponential per class (p = e / sum e).  `quad` = lane index inside the
+// quad (tid & 3); dextra / dout point at this (row, factor)'s first class.
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    return fmaxf(v, __shfl_xor(v, 2, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    return v + __shfl_xor(v, 2, 64);
+}
+__device__ __forceinline__ void cat_jacobian_quad32(const CatGeo& g, const float* __restrict__ lg, const float* __restrict__ gimg,
+                                                    int row, int fl, int quad, bool valid, const float* __restrict__ dextra,
+                                                    float* __restrict__ dout, float* __restrict__ dLf) {
+    constexpr int CC = 32, PER = 8;
+    const int c0 = quad * PER;
+    floatx4 ex[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        ex[h] = (dextra && valid) ? *reinterpret_cast<const floatx4*>(dextra + c0 + 4 * h) : floatx4{0.f, 0.f, 0.f, 0.f};
+    float v[PER], gr[PER];
+    const int rot = fl % CC;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        int r = c0 + j + rot;
+        if (r >= CC) r -= CC;
+        v[j] = lg[row * g.ld + fl * CC + r];
+        gr[j] = gimg[row * g.ld + fl * CC + r];
+    }
+    float m = v[0];
+#pragma unroll
+    for (int j = 1; j < PER; ++j) m = fmaxf(m, v[j]);
+    m = quad_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        v[j] = __expf(v[j] - m);
+        s += v[j];
+    }
+    const float inv = __builtin_amdgcn_rcpf(quad_sum(s));
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        v[j] *= inv;
+        dot += v[j] * gr[j];
+    }
+    dot = quad_sum(dot);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        floatx4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = valid ? v[4 * h + j] * (gr[4 * h + j] - dot) + ex[h][j] : 0.f;
+            dLf[frag_idx(row, fl * CC + c0 + 4 * h + j)] = o[j];
+        }
+        if (dout && valid) *reinterpret_cast<floatx4*>(dout + c0 + 4 * h) = o;
+    }
+}
+
 // Full-width image (forward heads: all S logits of the tile at once, row stride S + 8): same swizzle, fl = global factor.
 struct CatFull {
     int D, C, S, ld;
@@ -195,6 +284,7 @@ __device__ __forceinline__ int cat_sample_reg(const CatFull& g, const float* __r
     float m = -INFINITY;
 #pragma unroll
     for (int c = 0; c < CC; ++c) m = fmaxf(m, v[c]);
+#ifdef BD_EXACT_MATH
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < CC; ++c) s += expf(v[c] - m);
@@ -214,6 +304,20 @@ __device__ __forceinline__ int cat_sample_reg(const CatFull& g, const float* __r
         if (r > best) { best = r; arg = c; }
     }
     return arg;
+#else
+    // argmax_c probs_c / q_c = argmax_c exp(v_c - m) / q_c: the two normalisations of the library's softmax are common
+    // positive factors.  One hardware exponential and one reciprocal per class instead of three libm exponentials and two
+    // divisions (the sample phase was a third of an observe step); the ratios differ from the library's by ~1e-7
+    // relative, i.e. a sample can differ only where two classes tie to that precision.
+    float best = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+        const float r = __expf(v[c] - m) * __builtin_amdgcn_rcpf(q[c]);
+        if (r > best) { best = r; arg = c; }
+    }
+    return arg;
+#endif
 }
 
 // generic C: logits from the image, draws from global memory

@@ -19,6 +19,17 @@
 
 namespace bd {
 
+// Diagnostic (-DBD_STAMPS builds only): s_memtime of thread 0 of workgroup 0 at the phase boundaries of step t == 5.
+#ifdef BD_STAMPS
+__device__ unsigned long long g_catstamps[64];
+#define CAT_STAMP(slot)                                                                                    \
+    do {                                                                                                   \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && t == 5) g_catstamps[slot] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define CAT_STAMP(slot)
+#endif
+
 // gather-sum of the state columns of a first layer: out[row][col] = scale[row] * sum_f w[row][f] * WT[(f*C + idx[row][f]) * N + col]
 __device__ __forceinline__ void state_gather(const CatGeo& g, const float* __restrict__ WT, int N, const int* __restrict__ sidx_l,
                                              const float* __restrict__ sw_l, const float* __restrict__ scale_l,
@@ -76,17 +87,28 @@ __device__ __forceinline__ void state_to_indices(const CatGeo& g, const float* _
     }
 }
 
-// dense one-hot rows (scaled) from the indices: dst rows are global, row stride ld
+// dense one-hot rows (scaled) from the indices: dst rows are global, row stride ld.  One thread per (row, factor) writes
+// its C floats (16-byte stores when C and the row stride allow): no per-element index arithmetic.
 __device__ __forceinline__ void write_onehot(const CatGeo& g, const int* __restrict__ sidx_l, const float* __restrict__ sw_l,
                                              const float* __restrict__ scale_l, float* __restrict__ dst_row0, size_t ld,
                                              int rows_valid) {
-    for (int i = bd_tid(); i < 16 * g.S; i += blockDim.x) {
-        const int row = i / g.S, k = i - row * g.S;
+    const bool vec = (g.C & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)dst_row0) & 15) == 0;
+    for (int i = bd_tid(); i < 16 * g.D; i += blockDim.x) {
+        const int row = i / g.D, f = i - row * g.D;
         if (row >= rows_valid) continue;
-        const int f = k / g.C, c = k - f * g.C;
-        float v = (sidx_l[row * g.D + f] == c) ? sw_l[row * g.D + f] : 0.f;
+        const int hot = sidx_l[i];
+        float v = sw_l[i];
         if (scale_l) v *= scale_l[row];
-        dst_row0[(size_t)row * ld + k] = v;
+        float* p = dst_row0 + (size_t)row * ld + f * g.C;
+        if (vec) {
+            for (int c = 0; c < g.C; c += 4) {
+                floatx4 o = floatx4{0.f, 0.f, 0.f, 0.f};
+                if ((hot & ~3) == c) o[hot & 3] = v;
+                *reinterpret_cast<floatx4*>(p + c) = o;
+            }
+        } else {
+            for (int c = 0; c < g.C; ++c) p[c] = (c == hot) ? v : 0.f;
+        }
     }
 }
 
@@ -122,6 +144,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
 
     for (int t = 0; t < a.T; ++t) {
         const size_t tb = (size_t)t * a.B;
+        CAT_STAMP(0);
         // ---- A: mask, action fragments ----
         if (threadIdx.x < 16)
             mrow[threadIdx.x] = (a.nonterm && row0 + (int)threadIdx.x < a.B) ? a.nonterm[tb + row0 + threadIdx.x] : 1.f;
@@ -131,10 +154,13 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
             af[frag_idx(r, k)] = (grow < a.B && k < a.A) ? a.actions[(tb + grow) * a.A + k] : 0.f;
         }
         lds_barrier();
+        CAT_STAMP(1);
         // ---- A2: W_es s~ as a gather; the masked state for the embed weight gradient ----
         state_gather(g, a.w_embed_sT, a.Be, sidx_l, sw_l, mrow, xs);
+        CAT_STAMP(2);
         if (a.sv_s) write_onehot(g, sidx_l, sw_l, mrow, a.sv_s + (tb + row0) * S, (size_t)S, rows_valid);
         lds_barrier();
+        CAT_STAMP(3);
         // ---- B: x = ELU(W_es s~ + W_ea a + b_e) ----
         {
             const Seg segs[1] = {{af, a.w_embed_a, Kb_a}};
@@ -151,6 +177,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
             });
         }
         lds_barrier();
+        CAT_STAMP(4);
         // ---- C: GRU ----
         gru_tile(xf, h_cur, Kb_h, a.Be, gw, [&](int nb, floatx4 R, floatx4 Z, floatx4 NI, floatx4 NH) {
             const int col = nb * 16 + (lane & 15);
@@ -173,6 +200,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
             }
         });
         lds_barrier();
+        CAT_STAMP(5);
         // ---- D: posterior hidden ----
         tile_linear<1, kNI>(h_nxt, Kb_h, a.w_q1h, a.b_q1, a.Hd, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
@@ -186,16 +214,20 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
             }
         });
         lds_barrier();
+        CAT_STAMP(6);
         // ---- E: posterior logits, sample ----
         cat_head_forward_full(gf, qf, Kb_hd, a.w_q2, a.b_q2, a.q_post + (tb + row0) * S, a.post_logits + (tb + row0) * S,
                               rows_valid, lg, sidx_l);
+        CAT_STAMP(7);
         for (int i = threadIdx.x; i < 16 * g.D; i += blockDim.x) {
             const int row = i / g.D;
             sw_l[i] = row < rows_valid ? 1.f : 0.f;
             if (row < rows_valid) a.sidx[(tb + row0) * g.D + i] = (unsigned char)sidx_l[i];
         }
         lds_barrier();
+        CAT_STAMP(8);
         write_onehot(g, sidx_l, sw_l, nullptr, a.feat + (tb + row0) * F + a.Be, (size_t)F, rows_valid);
+        CAT_STAMP(9);
         float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
     }
 }
@@ -224,38 +256,53 @@ __device__ __forceinline__ void cat_head_backward(const CatGeo& g, bool have_car
     for (int ch = 0; ch < g.NCH; ++ch) {
         const int n = g.cols(ch);
         // (a) g = carry through the embed layer's state columns + heads' gradient; logits staged beside it
+        cat_stage(g, ch, logits_row0, (size_t)g.S, rows_valid, 0.f, lgs);
         if (have_carry) {
             const Seg seg[1] = {{dE, wt_embed_s + (size_t)ch * (g.CW / 16) * Kb_h * kFragFloats, Kb_h}};
-            tile_linear_g<1, 1>(seg, nullptr, n, [&](int, int nb, floatx4 a4) {
-                const int colc = nb * 16 + (lane & 15);
-                if (colc >= n) return;
-                const int fl = colc / g.C, c = colc - fl * g.C;
+            tile_linear_pre<1, 1>(
+                seg, nullptr, n,
+                [&](int, int nb) {          // the heads' gradient for this accumulator: requested before the contraction
+                    Pre4 p;
+                    const int colc = nb * 16 + (lane & 15);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * (lane >> 4) + r;
-                    float v = 0.f;
-                    if (row < rows_valid)
-                        v = a4[r] * (scale_l ? scale_l[row] : 1.f) + dstate_row0[(size_t)row * ld_ds + ch * g.CW + colc];
-                    pl[g.addr(row, fl, c)] = v;
-                }
-            });
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 4 * (lane >> 4) + r;
+                        p.v[r] = (colc < n && row < rows_valid) ? dstate_row0[(size_t)row * ld_ds + ch * g.CW + colc] : 0.f;
+                    }
+                    return p;
+                },
+                [&](int, int nb, floatx4 a4, const Pre4& p) {
+                    const int colc = nb * 16 + (lane & 15);
+                    if (colc >= n) return;
+                    const int fl = colc / g.C, c = colc - fl * g.C;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 4 * (lane >> 4) + r;
+                        pl[g.addr(row, fl, c)] = row < rows_valid ? a4[r] * (scale_l ? scale_l[row] : 1.f) + p.v[r] : 0.f;
+                    }
+                });
         } else {
             cat_stage(g, ch, dstate_row0, ld_ds, rows_valid, 0.f, pl);
         }
-        cat_stage(g, ch, logits_row0, (size_t)g.S, rows_valid, 0.f, lgs);
         lds_barrier();
         // (b) straight-through Jacobian per (row, factor), + direct logit gradient (KL); out to HBM and into the fragment
         //     tile of this chunk's K blocks (columns beyond the chunk's factors stay zero from the kernel's start)
-        {
+        if (g.C == 32) {          // four lanes per (row, factor): every thread works, one exponential per class
+            const int nf = n / 32;
+            for (int i = tid; i < 16 * nf * 4; i += blockDim.x) {
+                const int grp = i >> 2, quad = i & 3;
+                const int row = grp / nf, fl = grp - row * nf;
+                const size_t gi = (size_t)row * g.S + ch * g.CW + fl * 32;
+                cat_jacobian_quad32(g, lgs, pl, row, fl, quad, row < rows_valid, dextra_row0 ? dextra_row0 + gi : nullptr,
+                                    dlogit_row0 ? dlogit_row0 + gi : nullptr, dLf);
+            }
+            const int npad = cdiv(n, 16) * 16 - n;
+            for (int i = tid; i < 16 * npad; i += blockDim.x) dLf[frag_idx(i / npad, n + i % npad)] = 0.f;
+        } else {
             const int nf = n / g.C;
             for (int i = tid; i < 16 * nf; i += blockDim.x) {
                 const int row = i / nf, fl = i - row * nf;
                 const size_t gi = (size_t)row * g.S + ch * g.CW + fl * g.C;
-                if (g.C == 32) {
-                    cat_jacobian_reg<32>(g, lgs, pl, row, fl, row < rows_valid, dextra_row0 ? dextra_row0 + gi : nullptr,
-                                         dlogit_row0 ? dlogit_row0 + gi : nullptr, dLf);
-                    continue;
-                }
                 cat_jacobian(g, lgs, pl, row, fl);
                 for (int c = 0; c < g.C; ++c) {
                     float v = 0.f;
@@ -333,14 +380,17 @@ __global__ __launch_bounds__(kThreads) void observe_cat_bwd_kernel(bd_observe_ca
         const int tid = bd_tid();
         const int lane = tid & 63, wave = bd_wave(tid);
         // mask of step t+1 (its input state is posterior_state_t * nonterminal_{t+1})
+        CAT_STAMP(16);
         if (tid < 16)
             mrow[tid] = (a.nonterm && t + 1 < a.T && row0 + tid < a.B) ? a.nonterm[tb + a.B + row0 + tid] : 1.f;
         lds_barrier();
+        CAT_STAMP(17);
         // ---- 1: d posterior logits_t, d posterior hidden ----
         floatx4 accQ[NACC];
         cat_head_backward<NACC>(g, t + 1 < a.T, dE, Kb_h, a.wt_embed_s, mrow, a.dfeat + (tb + row0) * F + a.Be, (size_t)F,
                                 a.post_logits + (tb + row0) * S, a.dpost_logits ? a.dpost_logits + (tb + row0) * S : nullptr,
                                 a.d_q2_out + (tb + row0) * S, a.wt_q2, a.Hd, rows_valid, pl, lgs, dLf, accQ);
+        CAT_STAMP(18);
 #pragma unroll
         for (int i = 0; i < NACC; ++i) {
             const int nb = wave + i * kWaves;
@@ -359,6 +409,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_bwd_kernel(bd_observe_ca
             }
         }
         lds_barrier();
+        CAT_STAMP(19);
         // ---- 3: total d belief_{t+1}, GRU gate gradients ----
         tile_linear<1, kNI>(dQ, Kb_hd, a.wt_q1h, nullptr, a.Be, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
@@ -390,6 +441,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_bwd_kernel(bd_observe_ca
             }
         });
         lds_barrier();
+        CAT_STAMP(20);
         // ---- 4: through W_ih / W_hh: d embed pre-activation (the carry to step t-1's head), d belief_t ----
         gru_tile_bwd(
             dR, dZ, dNI, dNH, Kb_h, a.Be, gw,
@@ -419,6 +471,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_bwd_kernel(bd_observe_ca
                 }
             });
         lds_barrier();
+        CAT_STAMP(21);
     }
 }
 
@@ -846,6 +899,12 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_bwd_kernel(bd_imagine_ca
 
 extern "C" {
 using namespace bd;
+
+#ifdef BD_STAMPS
+int bd_debug_catstamps(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_catstamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #define BD_CAT_GEO(who)                                                                                                     \
     const CatGeo g(a->D, a->C);                                                                                             \
