@@ -97,7 +97,7 @@ class ImagineBwdArgs(C.Structure):
          "wt_p2s"]) + [("wt_a", P * 3)] + _ptr_fields(
         ["wt_a4m", "wt_a4s", "start_feat", "feat", "prior_std", "action", "eps_action", "eps_prior", "sv_actor",
          "sv_act_stats", "sv_x", "sv_gates", "sv_p"]) + [("min_std", F32)] + _ptr_fields(["dfeat"]) + [
-        ("dentropy", F32)] + _ptr_fields(["d_actor_pre", "d_actor_out"]))
+        ("dentropy", F32)] + _ptr_fields(["d_actor_pre", "d_actor_out", "ent_weight"]))
 
 
 U8P = C.c_void_p
@@ -131,7 +131,7 @@ class ImagineCatBwdArgs(C.Structure):
         ["wt_embed_s", "wt_embed_a", "wt_ir", "wt_iz", "wt_in", "wt_hr", "wt_hz", "wt_hn", "wt_p1", "wt_p2"]) + [
         ("wt_a", P * 3)] + _ptr_fields(
         ["wt_a4m", "wt_a4s", "start_feat", "feat", "prior_logits", "action", "eps_action", "sv_actor", "sv_act_stats",
-         "sv_x", "sv_gates", "sv_p", "dfeat"]) + [("dentropy", F32)] + _ptr_fields(["d_actor_pre", "d_actor_out"]))
+         "sv_x", "sv_gates", "sv_p", "dfeat"]) + [("dentropy", F32)] + _ptr_fields(["d_actor_pre", "d_actor_out", "ent_weight"]))
 
 
 class PlanArgs(C.Structure):
@@ -193,6 +193,7 @@ _SIGS = {
     "bd_cem_refit": (I32, [P, I32, P, I32, I32, I32, I32, I32, P, P, P]),
     "bd_lambda_return_backward": (I32, [P, F32, I32, I32, F32, F32, P, P, P]),
     "bd_normal_nll": (I32, [P, I32, P, I32, I32, I32, F32, P, I32, P, I32, P, P]),
+    "bd_bernoulli_nll": (I32, [P, P, C.c_size_t, F32, P, P, I32, P, P]),
     "bd_kl_forward": (I32, [P, P, P, P, I32, I32, F32, I32, P, I32, P, P]),
     "bd_kl_backward": (I32, [P, P, P, P, I32, I32, F32, F32, F32, F32, P, I32, P, P, P, P, P]),
     "bd_sum": (I32, [P, C.c_size_t, P, I32, P, P]),

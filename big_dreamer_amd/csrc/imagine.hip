@@ -418,8 +418,9 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
                         float gm = 0.f, gr = 0.f;
                         if (grow < a.N && col < A) {
                             const float dxa = acc[r] * (1.f - p.act[r] * p.act[r]);          // through a = tanh(x)
-                            const float dmean = dxa + a.dentropy * p.dm[r];
-                            const float dstd = dxa * p.eps[r] + a.dentropy * p.ds[r];
+                            const float dent = a.ent_weight ? a.dentropy * a.ent_weight[tn + grow] : a.dentropy;
+                            const float dmean = dxa + dent * p.dm[r];
+                            const float dstd = dxa * p.eps[r] + dent * p.ds[r];
                             gm = dmean * (1.f - p.th[r] * p.th[r]);      // mean = scale * tanh(m / scale)
                             gr = dstd * p.sg[r];                          // std = softplus(r + c0) + min
                             a.d_actor_out[(tn + grow) * 2 * A + col] = gm;

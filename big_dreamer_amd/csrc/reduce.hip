@@ -52,6 +52,22 @@ __global__ __launch_bounds__(256) void normal_nll_kernel(const float* __restrict
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
+// -log Bernoulli(logits=x).prob(t) = binary_cross_entropy_with_logits(x, t) = max(x, 0) - x t + log1p(exp(-|x|))
+// (Dreamer._discount_loss, src/dreamer.py:239-251); d/dx = sigmoid(x) - t
+__global__ __launch_bounds__(256) void bernoulli_nll_kernel(const float* __restrict__ logits, const float* __restrict__ target,
+                                                            size_t n, float grad_scale, float* __restrict__ dlogits,
+                                                            double* __restrict__ partials) {
+    __shared__ double red[kWaves];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = logits[i], t = target[i];
+        s += (double)(fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x))));
+        if (dlogits) dlogits[i] = (1.f / (1.f + expf(-x)) - t) * grad_scale;
+    }
+    s = block_sum_d(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
 // torch.distributions.kl._kl_normal_normal
 __device__ __forceinline__ float kl_elem(float qm, float qs, float pm, float ps) {
     const float ratio = qs / ps;
@@ -455,6 +471,16 @@ int bd_normal_nll(const float* pred, int ldp, const float* target, int ldt, int 
                        grad_scale, dpred, ldd, (double*)ws);
     BD_CHECK_LAUNCH("bd_normal_nll");
     return finish((double*)ws, nb, scalars, slot, (hipStream_t)stream, "bd_normal_nll(final)");
+}
+
+int bd_bernoulli_nll(const float* logits, const float* target, size_t n, float grad_scale, float* dlogits, float* scalars,
+                     int slot, float* ws, void* stream) {
+    BD_REQUIRE(logits && target && scalars && ws && n > 0, "bd_bernoulli_nll: bad arguments");
+    const int nb = red_blocks(n);
+    hipLaunchKernelGGL(bernoulli_nll_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, logits, target, n, grad_scale,
+                       dlogits, (double*)ws);
+    BD_CHECK_LAUNCH("bd_bernoulli_nll");
+    return finish((double*)ws, nb, scalars, slot, (hipStream_t)stream, "bd_bernoulli_nll(final)");
 }
 
 int bd_kl_forward(const float* qm, const float* qs, const float* pm, const float* ps, int rows, int S, float free_nats,

@@ -27,7 +27,8 @@ def _hp_from_params(params: Dict[str, Any]) -> Dict[str, float]:
         grad_clip_norm=params["grad_clip_norm"], discount=params["discount"], disclam=params["disclam"],
         model_learning_rate=params["model_learning_rate"], actor_learning_rate=ac["actor_learning_rate"],
         value_learning_rate=ac["value_learning_rate"], adam_epsilon=params["adam_epsilon"],
-        weight_decay=params["weight_decay"], entropy_weight=ac["entropy_weight"], polyak_avg=ac["polyak_avg"])
+        weight_decay=params["weight_decay"], entropy_weight=ac["entropy_weight"], polyak_avg=ac["polyak_avg"],
+        discount_weight=params.get("discount_weight", 5.0))
 
 
 class Dreamer:
@@ -41,8 +42,7 @@ class Dreamer:
             raise NotImplementedError(f"{self.latent_distribution}  is yet yet implemented")     # as src/dreamer.py:108
         if params["ActorCritic"]["gradient_mixing"] != -1:
             raise NotImplementedError("gradient_mixing not yet implemented ")      # as src/dreamer.py:339
-        if params.get("use_discount", False):
-            raise NotImplementedError("use_discount=True is off the default hot path")
+        self.use_discount = bool(params.get("use_discount", False))
         if params.get("disable_cuda", False) or not torch.cuda.is_available():
             raise RuntimeError("big_dreamer_amd runs on MI355X only: there is no CPU path (disable_cuda=True is the "
                                "reference's own CPU mode)")
@@ -65,7 +65,8 @@ class Dreamer:
         obs_size = 3 * 64 * 64 if self.pixel_observation else env.observation_size
         self.dims = Dims(B=self.batch_size, L=self.seq_len, H=self.planning_horizon, Be=self.belief_size,
                          S=self.state_size, Hd=self.hidden_size, E=self.embedding_size, A=self.action_size,
-                         O=obs_size, pixel=self.pixel_observation, cat_D=cat_D, cat_C=cat_C)
+                         O=obs_size, pixel=self.pixel_observation, cat_D=cat_D, cat_C=cat_C,
+                         use_discount=self.use_discount)
         self.engine = DreamerEngine(self.dims, _hp_from_params(params), self.device, world_size=world_size,
                                     process_group=process_group)
         e = self.engine
@@ -83,7 +84,7 @@ class Dreamer:
              (lambda: _ref_init_dense(env.observation_size, self.hidden_size, self.embedding_size))),
             ("actor", lambda: _ref_init_dense(feat, self.hidden_size, 2 * self.action_size)),
             ("critic", lambda: _ref_init_dense(feat, self.hidden_size, 1)),
-        ):
+        ) + ((("discount_model", lambda: _ref_init_dense(feat, self.hidden_size, 1)),) if self.use_discount else ()):
             init[mod] = {k: v.detach().numpy() for k, v in build().state_dict().items()}
         init["critic_target"] = init["critic"]                # copy.deepcopy(self.critic), src/dreamer.py:50
         e.load_params(init)
@@ -104,6 +105,8 @@ class Dreamer:
         self.actor = ActorModel(self.belief_size, self.state_size, self.hidden_size, self.action_size, engine=e)
         self.critic = DenseModel(feat, self.hidden_size, 1, engine=e, module="critic", prefix="cri")
         self.critic_target = DenseModel(feat, self.hidden_size, 1, engine=e, module="critic_target", prefix="tgt")
+        if self.use_discount:       # src/dreamer.py:80-85
+            self.discount_model = DenseModel(feat, self.hidden_size, 1, engine=e, module="discount_model", prefix="dsc")
         self.buffer = ExperienceReplay(params["experience_size"], env.action_size, params["bit_depth"], px,
                                        env.observation_size, self.device)
         self.load(params)

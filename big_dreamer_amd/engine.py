@@ -25,7 +25,7 @@ import torch.nn.functional as Fnn
 
 from . import _cabi as cabi
 from .parallel import DataParallel
-from .synth import DENSE_LAYERS, MODEL_MODULES, Dims, param_shapes
+from .synth import DENSE_LAYERS, MODEL_MODULES, Dims, model_modules, param_shapes
 
 lib = cabi.lib
 ptr = cabi.ptr
@@ -33,7 +33,7 @@ ptr = cabi.ptr
 DEFAULT_HP = dict(
     kl_balance=0.8, kl_loss_weight=0.1, free_nats=3.0, grad_clip_norm=100.0, discount=0.995, disclam=0.95,
     model_learning_rate=2e-4, actor_learning_rate=4e-5, value_learning_rate=1e-4, adam_epsilon=1e-5,
-    weight_decay=1e-6, entropy_weight=1e-5, polyak_avg=1.0, min_std_dev=0.1,
+    weight_decay=1e-6, entropy_weight=1e-5, polyak_avg=1.0, min_std_dev=0.1, discount_weight=5.0,
 )
 
 # actor constants (src/models.py:479-503)
@@ -43,6 +43,7 @@ ACT_MEAN_SCALE = 5.0
 
 # scalar-board slots (raw sums; see include/bigdreamer_hip.h "losses")
 SLOT_OBS, SLOT_REW, SLOT_KL, SLOT_RET, SLOT_ENT, SLOT_VAL, SLOT_GN_MODEL, SLOT_GN_ACTOR, SLOT_GN_CRITIC = range(9)
+SLOT_DISC, SLOT_WOBJ = 9, 10       # use_discount=True: Bernoulli loss sum (model phase); weighted actor objective sum
 N_SLOTS = 16
 
 
@@ -246,13 +247,13 @@ class DreamerEngine:
         # measured incumbent (17.9 ms/step, 20.0 serial) -- see DESIGN.md section 5, row R11
         self.conv_hip = self.pixel and os.environ.get("BD_CONV", "hip") != "miopen"
         self.groups = {
-            "model": ParamGroup([(m, n, s) for m in MODEL_MODULES for n, s in shapes[m]], self.dev,
+            "model": ParamGroup([(m, n, s) for m in model_modules(d) for n, s in shapes[m]], self.dev,
                                 conv_storage=self.conv_hip),
             "actor": ParamGroup([("actor", n, s) for n, s in shapes["actor"]], self.dev),
             "critic": ParamGroup([("critic", n, s) for n, s in shapes["critic"]], self.dev),
             "critic_target": ParamGroup([("critic_target", n, s) for n, s in shapes["critic"]], self.dev, False),
         }
-        self._mod_group = {m: "model" for m in MODEL_MODULES}
+        self._mod_group = {m: "model" for m in model_modules(d)}
         self._mod_group.update(actor="actor", critic="critic", critic_target="critic_target")
         if params is not None:
             self.load_params(params)
@@ -457,10 +458,14 @@ class DreamerEngine:
                 add("model", f"enc{l}", self.W("encoder", f"model.{2 * l}.weight"), tr=(l > 0))
                 add("model", f"obs{l}", self.W("observation_model", f"model.{2 * l}.weight"), tr=True)
             add("model", f"rew{l}", self.W("reward_model", f"model.{2 * l}.weight"), tr=True)
+            if d.use_discount:
+                add("model", f"dsc{l}", self.W("discount_model", f"model.{2 * l}.weight"), tr=True)
             add("critic", f"cri{l}", self.W("critic", f"model.{2 * l}.weight"), tr=(l > 0))
             add("critic_target", f"tgt{l}", self.W("critic_target", f"model.{2 * l}.weight"), tr=True)
         if cat:     # heads on [h; one-hot s]: layer 0 = belief columns (packed) + a gather of the state columns (plain W^T)
             heads = [("model", "reward_model", "rew"), ("critic", "critic", "cri"), ("critic_target", "critic_target", "tgt")]
+            if d.use_discount:
+                heads.append(("model", "discount_model", "dsc"))
             if not self.pixel:
                 heads.append(("model", "observation_model", "obs"))
             for grp, mod, prefix in heads:
@@ -611,7 +616,7 @@ class DreamerEngine:
             rec.events[row].synchronize()
         h = rec.host.numpy()
         s = h[0, :N_SLOTS].copy()
-        for slot in (SLOT_RET, SLOT_ENT, SLOT_GN_ACTOR):
+        for slot in (SLOT_RET, SLOT_ENT, SLOT_GN_ACTOR, SLOT_WOBJ):
             s[slot] = h[1, slot]
         for slot in (SLOT_VAL, SLOT_GN_CRITIC):
             s[slot] = h[2, slot]
@@ -1175,6 +1180,14 @@ class DreamerEngine:
                                                             sidx=self._buf[feat_tag + "sidx"] if cat else None)
 
         inv_rows = self.dp.mean_grad_scale(N)
+        dc_state = None
+        if d.use_discount:      # _discount_loss (src/dreamer.py:239-251): Bernoulli(logits).log_prob(nonterminal), weight 5
+            dc_out, dc_acts, dc_layers = self.dense_forward("discount_model", "dsc", "dc", feat, F, N, 1,
+                                                            sidx=self._buf[feat_tag + "sidx"] if cat else None)
+            d_dc = self.buf("d_dc_out", N, 1)
+            cabi.check(lib.bd_bernoulli_nll(ptr(dc_out), ptr(nonterm[:-1]), N, hp["discount_weight"] * inv_rows, ptr(d_dc), sc,
+                                            SLOT_DISC, ws, st))
+            dc_state = (d_dc, dc_acts, dc_layers)
         d_om, d_rw = self.buf("d_om_out", N, d.O), self.buf("d_rw_out", N, 1)
         cabi.check(lib.bd_normal_nll(ptr(om_out), d.O, ptr(obs_t), d.O, N, d.O, inv_rows, ptr(d_om), d.O, sc, SLOT_OBS, ws, st))
         cabi.check(lib.bd_normal_nll(ptr(rw_out), 1, ptr(rewards[:-1]), 1, N, 1, inv_rows, ptr(d_rw), 1, sc, SLOT_REW, ws, st))
@@ -1229,6 +1242,13 @@ class DreamerEngine:
             self.mlp_backward(N, d_om, d.O, om_layers, om_acts + [None], om_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F)
             self.mlp_backward(N, d_rw, 1, rw_layers, rw_acts + [None], rw_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F,
                               accumulate=True)
+        dc_dpre = None
+        if dc_state is not None:
+            d_dc, dc_acts, dc_layers = dc_state
+            dc_dpre = [self.buf(f"dc_dpre{l}", N, d.Hd) for l in range(DENSE_LAYERS)] + [d_dc]
+            self.mlp_backward(N, d_dc, 1, dc_layers, dc_acts + [None], dc_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F,
+                              accumulate=True)
+        self._dc_wgrad = (dc_dpre, dc_state[1]) if dc_state is not None else None
         # prior head: KL gradient on (mean, std) -> belief part of dfeat
         p_out, p_hid = self._buf["p_out"], self._buf["p_hid"]
         HO = d.head_out
@@ -1335,6 +1355,8 @@ class DreamerEngine:
                Gt("belief_posterior.model.2.bias"))
         dense_sizes = lambda i, o: [i] + [d.Hd] * DENSE_LAYERS + [o]
         self._dense_wgrads(wb, "reward_model", N, rw_dpre, feat, F, rw_acts, dense_sizes(F, 1))
+        if self._dc_wgrad is not None:
+            self._dense_wgrads(wb, "discount_model", N, self._dc_wgrad[0], feat, F, self._dc_wgrad[1], dense_sizes(F, 1))
         if not self.pixel:      # (pixel mode: conv weight gradients came from MIOpen above)
             self._dense_wgrads(wb, "observation_model", N, om_dpre, feat, F, om_acts, dense_sizes(F, d.O))
             self._dense_wgrads(wb, "encoder", N, enc_dpre, obs_t, d.O, enc_acts, dense_sizes(d.O, d.E))
@@ -1387,20 +1409,35 @@ class DreamerEngine:
         cabi.check(lib.bd_sum(ptr(returns), Mi, sc, SLOT_RET, ws, st))
         cabi.check(lib.bd_sum(ptr(ent), Mi, sc, SLOT_ENT, ws, st))
         inv_mi = self.dp.mean_grad_scale(Mi)
+        wts = dret = None
+        if d.use_discount:
+            # Cumulative discount weights of the actor objective and the value loss (src/dreamer.py:323-326,346-351,
+            # 374-379): discount * round(sigmoid(discount head)), trajectory 0 forced to 1 at every step (the reference's
+            # `discount_arr[:, 0, 0] = 1.0`), cumprod over time.  No gradient flows through them (round; frozen head):
+            # a handful of elementwise torch ops on (Hm, N) -- this switch is off by default (conf/config.yaml:76).
+            dl, _, _ = self.dense_forward("discount_model", "dsc", "idc", ifeat, F, Mi, 1, sidx=isidx)
+            arr = hp["discount"] * torch.round(torch.sigmoid(dl.view(Hm, N)))
+            arr[:, 0] = 1.0
+            wts = self.buf(ptag + "disc_w", Mi)
+            wts.view(Hm, N).copy_(torch.cumprod(arr, 0))
+            ew_ = hp["entropy_weight"] if hp["entropy_weight"] != -1 else 0.0
+            self.scalars[SLOT_WOBJ] = (wts * (returns + ew_ * ent)).sum()
+            dret = self.buf("dret_w", Mi)
+            torch.mul(wts, -inv_mi, out=dret)
         if par is not None:
             ev_ret = torch.cuda.Event()
             ev_ret.record(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev_ret)
-                self._critic_phase(ifeat, returns, Mi, F, inv_mi, self.red_ws_side, isidx)
+                self._critic_phase(ifeat, returns, Mi, F, inv_mi, self.red_ws_side, isidx, wts)
                 self._ev_cr_done[par] = torch.cuda.Event()
                 self._ev_cr_done[par].record(self._side)
         elif self.overlap_critic:    # fork: critic phase on the side stream, actor backward continues here
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
-                self._critic_phase(ifeat, returns, Mi, F, inv_mi, self.red_ws_side, isidx)
+                self._critic_phase(ifeat, returns, Mi, F, inv_mi, self.red_ws_side, isidx, wts)
         d_r, d_v = self.buf("d_ir_out", Mi), self.buf("d_iv_out", Mi)
-        cabi.check(lib.bd_lambda_return_backward(None, -inv_mi, Hm, N, hp["discount"], hp["disclam"], ptr(d_r), ptr(d_v), st))
+        cabi.check(lib.bd_lambda_return_backward(ptr(dret), -inv_mi, Hm, N, hp["discount"], hp["disclam"], ptr(d_r), ptr(d_v), st))
         difeat = self.buf("difeat", Mi, F)
         with self.span("img_heads_bwd"):
             self.mlp_backward(Mi, d_r, 1, r_layers, r_acts + [None], None, din0=difeat, ld0=F, w0=F)
@@ -1431,6 +1468,7 @@ class DreamerEngine:
         c.dentropy = -hp["entropy_weight"] * inv_mi if hp["entropy_weight"] != -1 else 0.0
         d_apre, d_aout = self.buf("d_actor_pre", DENSE_LAYERS, Mi, d.Hd), self.buf("d_actor_out", Mi, 2 * d.A)
         c.d_actor_pre, c.d_actor_out = ptr(d_apre), ptr(d_aout)
+        c.ent_weight = ptr(wts)
         with self.span("imagine_bwd"):
             cabi.check((lib.bd_imagine_cat_backward if d.categorical else lib.bd_imagine_backward)(C.byref(c), st))
         if self.pipeline:       # last reader of the world model in this step
@@ -1452,12 +1490,12 @@ class DreamerEngine:
         if par is not None:
             pass
         elif not self.overlap_critic:
-            self._critic_phase(ifeat, returns, Mi, F, inv_mi, red_ws, isidx)
+            self._critic_phase(ifeat, returns, Mi, F, inv_mi, red_ws, isidx, wts)
         else:
             torch.cuda.current_stream().wait_stream(self._side)     # join before the next step reuses ifeat / returns
         self._counts = dict(N=N, Mi=Mi, S=(d.cat_D if d.categorical else d.S), sum_form=sum_form)
 
-    def _critic_phase(self, ifeat, returns, Mi: int, F: int, inv_mi: float, red_ws: torch.Tensor, isidx=None) -> None:
+    def _critic_phase(self, ifeat, returns, Mi: int, F: int, inv_mi: float, red_ws: torch.Tensor, isidx=None, wts=None) -> None:
         """Critic update (src/dreamer.py:370-391) on the current stream: forward on the detached imagined features,
         Normal(v, 1) NLL against the detached returns, dgrad chain, grouped weight gradients, clip + Adam, re-pack."""
         d, hp = self.d, self.hp
@@ -1466,6 +1504,10 @@ class DreamerEngine:
             c_out, c_acts, c_layers = self.dense_forward("critic", "cri", "ic", ifeat, F, Mi, 1, sidx=isidx)
             d_c = self.buf("d_ic_out", Mi, 1)
             cabi.check(lib.bd_normal_nll(ptr(c_out), 1, ptr(returns), 1, Mi, 1, inv_mi, ptr(d_c), 1, sc, SLOT_VAL, ptr(red_ws), st))
+            if wts is not None:     # use_discount=True: -(discount * log_prob).mean() (src/dreamer.py:378-379)
+                d_c.view(Mi).mul_(wts)
+                diff = c_out.view(Mi) - returns
+                self.scalars[SLOT_VAL] = (wts * (0.5 * diff * diff + 0.9189385332046727)).sum()
             c_dpre = [self.buf(f"ic_dpre{l}", Mi, d.Hd) for l in range(DENSE_LAYERS)] + [d_c]
             self.mlp_backward(Mi, d_c, 1, c_layers, c_acts + [None], c_dpre[:-1] + [None])
         wc = self._wbatch["critic"]
@@ -1499,12 +1541,21 @@ class DreamerEngine:
             x = np.maximum(mean, f32(hp["free_nats"]))
             kl = f32(hp["kl_balance"]) * x + f32(1 - hp["kl_balance"]) * x
         ew = f32(hp["entropy_weight"]) if hp["entropy_weight"] != -1 else f32(0)
-        return {
+        model_loss = obs + rew + kl * f32(hp["kl_loss_weight"])
+        objective = s[SLOT_RET] + ew * s[SLOT_ENT]
+        out = {}
+        if self.d.use_discount:         # src/dreamer.py:287-290, 346-352
+            disc = s[SLOT_DISC] / N
+            model_loss = model_loss + disc * f32(hp["discount_weight"])
+            out["discount_loss"] = float(disc)
+            objective = s[SLOT_WOBJ]
+        out.update({
             "observation_loss": float(obs), "reward_loss": float(rew), "kl_loss": float(kl),
-            "model_loss": float(obs + rew + kl * f32(hp["kl_loss_weight"])),
-            "actor_loss": float(-(s[SLOT_RET] + ew * s[SLOT_ENT]) / Mi),
+            "model_loss": float(model_loss),
+            "actor_loss": float(-objective / Mi),
             "policy_entropy": float(s[SLOT_ENT] / Mi),
             "value_loss": float(s[SLOT_VAL] / Mi),
             "grad_norm_model": float(math.sqrt(s[SLOT_GN_MODEL])), "grad_norm_actor": float(math.sqrt(s[SLOT_GN_ACTOR])),
             "grad_norm_critic": float(math.sqrt(s[SLOT_GN_CRITIC])),
-        }
+        })
+        return out

@@ -34,6 +34,7 @@ class Dims:
     pixel: bool = False   # 64x64x3 pixel observations (conv encoder / decoder, src/models.py:319-362,527-564)
     cat_D: int = 0        # latent_distribution="Categorical": discrete_latent_dimensions (0 = Gaussian latents)
     cat_C: int = 0        #                                    discrete_latent_classes; S must equal cat_D * cat_C (src/planet.py:56-57)
+    use_discount: bool = False   # discount_model head + Bernoulli loss + discounted actor objective (src/dreamer.py:80-86,239-251,346-351)
 
     def __post_init__(self):
         assert (self.cat_D == 0) == (self.cat_C == 0) and (self.cat_D == 0 or self.S == self.cat_D * self.cat_C), \
@@ -70,6 +71,7 @@ CONFIG1 = Dims(B=50, L=50, H=15, Be=32, S=30, Hd=32, E=1024, A=1, O=3)     # BAS
 CONFIG2 = Dims()                                                           # BASELINE.json configs[1]
 PIXEL_SHAPE = (3, 64, 64)
 TINY = Dims(B=3, L=5, H=4, Be=24, S=6, Hd=20, E=40, A=2, O=5, n_entropy=100)
+TINY_DISCOUNT = Dims(B=3, L=5, H=4, Be=24, S=6, Hd=20, E=40, A=2, O=5, n_entropy=100, use_discount=True)
 TINY_PIXEL = Dims(B=2, L=4, H=3, Be=24, S=6, Hd=20, E=1024, A=2, O=12288, pixel=True)      # Identity after Flatten
 TINY_PIXEL_LIN = Dims(B=2, L=3, H=3, Be=20, S=5, Hd=24, E=48, A=1, O=12288, pixel=True)     # Linear(1024, E) tail
 CONFIG3 = Dims(A=17, O=12288, pixel=True)                                                   # BASELINE.json configs[2]
@@ -129,7 +131,7 @@ def param_shapes(d: Dims) -> Dict[str, List[Tuple[str, Tuple[int, ...]]]]:
     else:
         enc = strip(_mlp_shapes("x", [d.O] + hid + [d.E]))
         obs = strip(_mlp_shapes("x", [feat] + hid + [d.O]))
-    return {
+    out = {
         "transition_model": tm,
         "observation_model": obs,
         "reward_model": strip(_mlp_shapes("x", [feat] + hid + [1])),
@@ -137,11 +139,19 @@ def param_shapes(d: Dims) -> Dict[str, List[Tuple[str, Tuple[int, ...]]]]:
         "actor": strip(_mlp_shapes("x", [feat] + hid + [2 * d.A])),
         "critic": strip(_mlp_shapes("x", [feat] + hid + [1])),
     }
+    if d.use_discount:      # DenseModel(belief + state, hidden) (src/dreamer.py:80-85); joins the model optimiser last (:167-169)
+        out["discount_model"] = strip(_mlp_shapes("x", [feat] + hid + [1]))
+    return out
 
 
 # Order in which the reference concatenates the world-model parameters for its optimiser
 # (src/dreamer.py:160-165).
 MODEL_MODULES = ("transition_model", "observation_model", "reward_model", "encoder")
+
+
+def model_modules(d: "Dims"):
+    """Modules of the world-model optimiser in the reference's parameter order (src/dreamer.py:160-169)."""
+    return MODEL_MODULES + (("discount_model",) if d.use_discount else ())
 
 
 def make_params(d: Dims, seed: int = 0) -> Dict[str, Dict[str, np.ndarray]]:

@@ -323,6 +323,8 @@ typedef struct {
     /* outputs for bd_wgrad */
     float* d_actor_pre;     /* [4][Hm x N x Hd]                                                     */
     float* d_actor_out;     /* [Hm x N x 2A]                                                        */
+    const float* ent_weight; /* optional [Hm x N] per-element factor on dentropy (use_discount=True: the cumulative
+                              * discount weights of the actor objective, src/dreamer.py:346-351), or NULL          */
 } bd_imagine_bwd_args;
 int bd_imagine_backward(const bd_imagine_bwd_args* a, void* stream);
 
@@ -462,6 +464,7 @@ typedef struct {
     const float* dfeat;          /* [Hm x N x (Be+S)] from the reward / value heads                            */
     float dentropy;
     float* d_actor_pre; float* d_actor_out;                    /* as bd_imagine_bwd_args                      */
+    const float* ent_weight;     /* as bd_imagine_bwd_args, or NULL                                              */
 } bd_imagine_cat_bwd_args;
 int bd_imagine_cat_backward(const bd_imagine_cat_bwd_args* a, void* stream);
 
@@ -507,6 +510,11 @@ int bd_cem_refit(const float* returns, int ret_steps, const float* actions, int 
  * (-Independent(Normal(pred,1)).log_prob(target); dpred may be NULL) */
 int bd_normal_nll(const float* pred, int ldp, const float* target, int ldt, int rows, int D,
                   float grad_scale, float* dpred, int ldd, float* scalars, int slot, float* ws, void* stream);
+/* Dreamer._discount_loss (src/dreamer.py:239-251, use_discount=True): RAW sum over n elements of
+ * -log Bernoulli(logits).prob(target) into scalars[slot]; dlogits (may be NULL) = (sigmoid(logit) - target) * grad_scale. */
+int bd_bernoulli_nll(const float* logits, const float* target, size_t n, float grad_scale, float* dlogits, float* scalars,
+                     int slot, float* ws, void* stream);
+
 /* balanced form (sum_form=0): scalars[slot] = sum of elementwise KL(N(qm,qs) || N(pm,ps));
  * summed form  (sum_form=1, kl_balance == -1): scalars[slot] = sum_rows max(sum_S KL, free_nats) */
 int bd_kl_forward(const float* qm, const float* qs, const float* pm, const float* ps, int rows, int S,

@@ -407,7 +407,7 @@ def mpc_planner(P, belief: Tensor, state: Tensor, action_size: int, planning_hor
 DEFAULT_HP = dict(
     kl_balance=0.8, kl_loss_weight=0.1, free_nats=3.0, grad_clip_norm=100.0, discount=0.995, disclam=0.95,
     model_learning_rate=2e-4, actor_learning_rate=4e-5, value_learning_rate=1e-4, adam_epsilon=1e-5,
-    weight_decay=1e-6, entropy_weight=1e-5, planning_horizon=15,
+    weight_decay=1e-6, entropy_weight=1e-5, planning_horizon=15, discount_weight=5.0,
 )
 
 MODEL_MODULES = ("transition_model", "observation_model", "reward_model", "encoder")   # dreamer.py:160-165
@@ -424,7 +424,10 @@ class OracleDreamer:
         self.cat = tuple(self.hp["categorical"]) if self.hp.get("categorical") else None
         self.P = {mod: {k: torch.tensor(v, dtype=torch.float32, requires_grad=(mod != "critic_target"))
                         for k, v in sd.items()} for mod, sd in P_numpy.items()}
-        self.model_params = [p for mod in MODEL_MODULES for p in self.P[mod].values()]
+        # use_discount=True: the discount head joins the model optimiser last (src/dreamer.py:167-169)
+        self.use_discount = "discount_model" in self.P
+        self.model_modules = MODEL_MODULES + (("discount_model",) if self.use_discount else ())
+        self.model_params = [p for mod in self.model_modules for p in self.P[mod].values()]
         self.actor_params = list(self.P["actor"].values())
         self.critic_params = list(self.P["critic"].values())
         self.opt = {"model": AdamState(self.model_params), "actor": AdamState(self.actor_params),
@@ -457,14 +460,22 @@ class OracleDreamer:
             obs_loss = normal_nll_mean(dense_on_features(beliefs, post_states, P["observation_model"]), obs[1:])
         rew_pred = dense_on_features(beliefs, post_states, P["reward_model"])
         rew_loss = normal_nll_mean(rew_pred, rewards[:-1].unsqueeze(-1))
+        self._discount_loss = None
+        if self.use_discount:   # _discount_loss (src/dreamer.py:239-251): -mean log Bernoulli(logits).prob(nonterminal)
+            logits = dense_on_features(beliefs, post_states, P["discount_model"])
+            self._discount_loss = F.binary_cross_entropy_with_logits(logits, nonterm[:-1].float(), reduction="none").sum(-1).mean()
         if self.cat:
             kl = kl_loss_categorical(post_params[0], prior_params[0], hp["kl_balance"], hp["free_nats"])
             model_loss = obs_loss + rew_loss + kl * hp["kl_loss_weight"]                       # :285
+            if self._discount_loss is not None:
+                model_loss = model_loss + self._discount_loss * hp["discount_weight"]          # :287-289
             inter = dict(embeddings=emb, beliefs=beliefs, prior_states=prior_states, prior_logits=prior_params[0],
                          posterior_states=post_states, posterior_logits=post_params[0], reward_pred=rew_pred)
             return model_loss, obs_loss, rew_loss, kl, inter
         kl = kl_loss(post_params, prior_params, hp["kl_balance"], hp["free_nats"])
         model_loss = obs_loss + rew_loss + kl * hp["kl_loss_weight"]                           # :285
+        if self._discount_loss is not None:
+            model_loss = model_loss + self._discount_loss * hp["discount_weight"]              # :287-289
         inter = dict(embeddings=emb, beliefs=beliefs, prior_states=prior_states, prior_means=prior_params[0],
                      prior_stds=prior_params[1], posterior_states=post_states, posterior_means=post_params[0],
                      posterior_stds=post_params[1], reward_pred=rew_pred)
@@ -500,6 +511,8 @@ class OracleDreamer:
         model_loss, obs_loss, rew_loss, kl, inter = self.world_model_forward(batch, noise)
         logs.update(observation_loss=obs_loss.item(), reward_loss=rew_loss.item(), kl_loss=kl.item(),
                     model_loss=model_loss.item())
+        if self._discount_loss is not None:
+            logs["discount_loss"] = self._discount_loss.item()                                 # :290
         grads = torch.autograd.grad(model_loss, self.model_params, allow_unused=True)
         grads = [torch.zeros_like(p) if g is None else g.clone() for g, p in zip(grads, self.model_params)]
         model_grads = [g.clone() for g in grads] if keep else None
@@ -512,7 +525,7 @@ class OracleDreamer:
         # FreezeParameters(model_modules): world-model weights are constants here (dreamer.py:313);
         # they are the *post-update* weights.
         Pf = dict(P)
-        for mod in MODEL_MODULES + ("critic_target",):
+        for mod in self.model_modules + ("critic_target",):
             Pf[mod] = {k: v.detach() for k, v in P[mod].items()}
         img_b, img_s, _, ent = imagine_ahead(Pf, post_states, beliefs, hp["planning_horizon"], noise["action"],
                                              noise["entropy"], noise["img_prior"], self.cat)
@@ -520,6 +533,17 @@ class OracleDreamer:
         value_pred = dense_on_features(img_b, img_s, Pf["critic_target"])                     # :322
         returns = lambda_return(img_reward, value_pred, value_pred[-1], hp["discount"], hp["disclam"])
         objective = returns + hp["entropy_weight"] * ent.unsqueeze(-1)                         # :346
+        wts = None
+        if self.use_discount:
+            # discount_arr = discount * round(Bernoulli(logits).probs) (:323-326; no gradient: round, frozen weights);
+            # `discount_arr[:, 0, 0] = 1.0` sets trajectory 0 at EVERY step (the comment says "the first one of each
+            # trajectory"; the indexing says otherwise -- reproduced as written); weights = cumprod over time (:349-351)
+            with torch.no_grad():
+                dl = dense_on_features(img_b, img_s, Pf["discount_model"])
+                arr = hp["discount"] * torch.round(torch.sigmoid(dl))
+                arr[:, 0, 0] = 1.0
+                wts = torch.cumprod(arr, 0)
+            objective = wts * objective
         actor_loss = -objective.mean()
         logs.update(actor_loss=actor_loss.item(), policy_entropy=ent.mean().item())
         agrads = [g.clone() for g in torch.autograd.grad(actor_loss, self.actor_params)]
@@ -530,7 +554,8 @@ class OracleDreamer:
         # critic (dreamer.py:370-391)
         v = dense_on_features(img_b.detach(), img_s.detach(), P["critic"])
         target = returns.detach()
-        value_loss = (0.5 * (target - v) ** 2 + HALF_LOG_2PI).mean()
+        nll = 0.5 * (target - v) ** 2 + HALF_LOG_2PI
+        value_loss = (wts * nll).mean() if wts is not None else nll.mean()                      # :378-381
         logs.update(value_loss=value_loss.item())
         cgrads = [g.clone() for g in torch.autograd.grad(value_loss, self.critic_params)]
         critic_grads = [g.clone() for g in cgrads] if keep else None

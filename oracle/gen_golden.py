@@ -160,9 +160,11 @@ def build_agent(dreamer_mod, d, P, **over):
     if d.categorical:
         over = dict(latent_distribution="Categorical", discrete_latent_dimensions=d.cat_D,
                     discrete_latent_classes=d.cat_C, **over)
+    if d.use_discount:
+        over = dict(use_discount=True, **over)
     agent = dreamer_mod.Dreamer(ref_params(d, **over), FakeEnv(d))
     for mod in ("transition_model", "observation_model", "reward_model", "encoder", "actor", "critic",
-                "critic_target"):
+                "critic_target") + (("discount_model",) if d.use_discount else ()):
         getattr(agent, mod).load_state_dict({k: torch.from_numpy(v.copy()) for k, v in P[mod].items()})
     return agent
 
@@ -245,10 +247,10 @@ def run_config(dreamer_mod, name: str, d: synth.Dims, full: bool, seed: int = 0,
             if step == 0:
                 agent.update_critic()      # exercised between steps (main.py:110-112)
             for k, v in logs.items():
-                out[f"step{step}.log.{k}"] = np.array(v, dtype=np.float64)
+                out[f"step{step}.log.{k}"] = np.array(float(v), dtype=np.float64)     # (discount_loss is logged as a tensor, :290)
             out[f"step{step}.grad_norms"] = np.array(norms[-3:], dtype=np.float64)
             for mod in ("transition_model", "observation_model", "reward_model", "encoder", "actor", "critic",
-                        "critic_target"):
+                        "critic_target") + (("discount_model",) if d.use_discount else ()):
                 for k, p in getattr(agent, mod).state_dict().items():
                     a = t2n(p)
                     store(out, f"step{step}.param.{mod}.{k}", a, full)
@@ -605,6 +607,7 @@ def main():
     run_config(dreamer_mod, "config1", synth.CONFIG1, full=False)
     run_config(dreamer_mod, "config2", synth.CONFIG2, full=False)
     run_config(dreamer_mod, "config3", synth.CONFIG3, full=False, seed=6)      # BASELINE configs[2], full size (~1 min)
+    run_config(dreamer_mod, "tiny_discount", synth.TINY_DISCOUNT, full=True, seed=9)   # use_discount=True
     main_planner(dreamer_mod)
     run_act(dreamer_mod)
     for name, (dd, sd_, ov) in CATEGORICAL_RUNS.items():
@@ -622,6 +625,7 @@ if __name__ == "__main__":
                     run_config_categorical(dm, name, dd, sd_, **ov)
                 continue
             {"config3": lambda: run_config(dm, "config3", synth.CONFIG3, full=False, seed=6),
+             "discount": lambda: run_config(dm, "tiny_discount", synth.TINY_DISCOUNT, full=True, seed=9),
              "act": lambda: run_act(dm)}[what]()
     elif "--planner-only" in sys.argv:       # regenerate only the planner / PlaNet vectors
         torch.manual_seed(0)

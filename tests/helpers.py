@@ -17,7 +17,8 @@ CASES = {
     "tiny_pixel_lin": (synth.TINY_PIXEL_LIN, 5, {}, False),
     "config1": (synth.CONFIG1, 0, {}, False),
     "config2": (synth.CONFIG2, 0, {}, False),
-    "config3": (synth.CONFIG3, 6, {}, False),       # BASELINE configs[2] at full size: 64x64 pixels, A=17, batch 50 x chunk 50
+    "config3": (synth.CONFIG3, 6, {}, False),
+    "tiny_discount": (synth.TINY_DISCOUNT, 9, {}, True),   # use_discount=True: discount head, Bernoulli loss, discounted actor objective       # BASELINE configs[2] at full size: 64x64 pixels, A=17, batch 50 x chunk 50
 }
 
 

@@ -98,7 +98,7 @@ def test_forward_pieces_vs_oracle(name):
                                           ("tiny_freenats0", False), ("config2", False),
                                           ("tiny_pixel", True), ("tiny_pixel_lin", True),
                                           ("tiny_pixel", "miopen"), ("tiny_pixel_lin", "miopen"),
-                                          ("config3", True)])
+                                          ("config3", True), ("tiny_discount", True), ("tiny_discount", False)])
 def test_train_steps_vs_oracle_and_golden(name, cluster, monkeypatch):
     """Two whole train steps: losses, clipped gradients, gradient norms, post-Adam weights -- with the observe
     scan run by the multi-CU cluster kernels (default) and by the single-workgroup kernels."""
@@ -131,7 +131,7 @@ def test_train_steps_vs_oracle_and_golden(name, cluster, monkeypatch):
             _rel(f"s{step}.grad_norms", [logs["grad_norm_model"], logs["grad_norm_actor"], logs["grad_norm_critic"]],
                  [gn["model"], gn["actor"], gn["critic"]], 1e-6, 1e-3, rep)
             coef = {k: min(1.0, od.hp["grad_clip_norm"] / (gn[k] + 1e-6)) for k in gn}
-            groups = {"model": (O.MODEL_MODULES, od.last["model_grads"]), "actor": (("actor",), od.last["actor_grads"]),
+            groups = {"model": (od.model_modules, od.last["model_grads"]), "actor": (("actor",), od.last["actor_grads"]),
                       "critic": (("critic",), od.last["critic_grads"])}
             for grp, (mods, grads) in groups.items():
                 i = 0
@@ -143,7 +143,7 @@ def test_train_steps_vs_oracle_and_golden(name, cluster, monkeypatch):
                         # gradients are long sums: tolerance relative to the tensor's own scale
                         _rel(f"s{step}.grad.{mod}.{k}", got, want, 2e-3 * scale + 1e-9, 2e-3, rep)
                         i += 1
-            for mod in list(O.MODEL_MODULES) + ["actor", "critic", "critic_target"]:
+            for mod in list(od.model_modules) + ["actor", "critic", "critic_target"]:
                 for k, p in od.P[mod].items():
                     got = eng.W(mod, k).detach().cpu().numpy()
                     # an Adam step moves a weight by <= lr (2e-4): agreement must be far below one step
@@ -177,7 +177,7 @@ def test_wide_action_vectors_vs_oracle(dims):
                 _rel(f"s{step}.{k}", logs[k], v, tol[0], tol[1], rep)
             gn = od.last["grad_norms"]
             coef = {k: min(1.0, od.hp["grad_clip_norm"] / (gn[k] + 1e-6)) for k in gn}
-            groups = {"model": (O.MODEL_MODULES, od.last["model_grads"]), "actor": (("actor",), od.last["actor_grads"]),
+            groups = {"model": (od.model_modules, od.last["model_grads"]), "actor": (("actor",), od.last["actor_grads"]),
                       "critic": (("critic",), od.last["critic_grads"])}
             for grp, (mods, grads) in groups.items():
                 i = 0

@@ -74,7 +74,7 @@ def test_train_steps(name):
         assert_close(f"step{step}.grad_norms", [gn["model"], gn["actor"], gn["critic"]],
                      g[f"step{step}.grad_norms"], 1e-6, 1e-4)
         coef = {k: min(1.0, od.hp["grad_clip_norm"] / (gn[k] + 1e-6)) for k in gn}
-        groups = {"model": (O.MODEL_MODULES, od.last["model_grads"]), "actor": (("actor",), od.last["actor_grads"]),
+        groups = {"model": (od.model_modules, od.last["model_grads"]), "actor": (("actor",), od.last["actor_grads"]),
                   "critic": (("critic",), od.last["critic_grads"])}
         for grp, (mods, grads) in groups.items():
             i = 0
@@ -85,7 +85,7 @@ def test_train_steps(name):
                     scale = float(np.abs(gg).max()) + 1e-12
                     compare_tensor(g, f"step{step}.grad.{mod}.{k}", gg, full, atol=2e-5 * scale + 1e-9, rtol=2e-4)
                     i += 1
-        for mod in list(O.MODEL_MODULES) + ["actor", "critic", "critic_target"]:
+        for mod in list(od.model_modules) + ["actor", "critic", "critic_target"]:
             for k, p in od.P[mod].items():
                 # one Adam step moves a weight by <= lr (2e-4): weights must agree to well below that
                 compare_tensor(g, f"step{step}.param.{mod}.{k}", p.detach().numpy(), full, atol=2e-6, rtol=1e-6)
@@ -232,7 +232,7 @@ def test_categorical_scan_against_reference(name):
         gn = od.last["grad_norms"]
         assert_close(f"step{step}.grad_norms", [gn["model"], gn["actor"], gn["critic"]], g[f"step{step}.grad_norms"], 1e-6, 1e-4)
         coef = {k: min(1.0, od.hp["grad_clip_norm"] / (gn[k] + 1e-6)) for k in gn}
-        groups = {"model": (O.MODEL_MODULES, od.last["model_grads"]), "actor": (("actor",), od.last["actor_grads"]),
+        groups = {"model": (od.model_modules, od.last["model_grads"]), "actor": (("actor",), od.last["actor_grads"]),
                   "critic": (("critic",), od.last["critic_grads"])}
         for grp, (mods, grads) in groups.items():
             i = 0
@@ -242,6 +242,6 @@ def test_categorical_scan_against_reference(name):
                     scale = float(np.abs(gg).max()) + 1e-12
                     compare_tensor(g, f"step{step}.grad.{mod}.{k}", gg, full, atol=2e-5 * scale + 1e-9, rtol=2e-4)
                     i += 1
-        for mod in list(O.MODEL_MODULES) + ["actor", "critic", "critic_target"]:
+        for mod in list(od.model_modules) + ["actor", "critic", "critic_target"]:
             for k, p in od.P[mod].items():
                 compare_tensor(g, f"step{step}.param.{mod}.{k}", p.detach().numpy(), full, atol=2e-6, rtol=1e-6)
