@@ -242,3 +242,28 @@ def test_exact_math_build():
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("EXACT_RESULT ")][-1][len("EXACT_RESULT "):])
     assert res["belief"] < 2e-6 and res["weight"] < 2e-6 and res["log"] < 1e-5, res
+
+
+def test_use_discount_on_the_surface():
+    """use_discount=True through Dreamer(params, env): the discount head exists with the reference's state_dict names, joins
+    the model optimiser last (src/dreamer.py:167-169) and train_step logs discount_loss (src/dreamer.py:290)."""
+    from big_dreamer_amd.config import load_config
+    from big_dreamer_amd.dreamer import Dreamer
+    d = synth.TINY_DISCOUNT
+
+    class Env:
+        action_size, observation_size = d.A, d.O
+
+    agent = Dreamer(load_config([f"belief_size={d.Be}", f"state_size={d.S}", f"hidden_size={d.Hd}", f"embedding_size={d.E}",
+                                 f"batch_size={d.B}", f"seq_len={d.L}", f"planning_horizon={d.H}", "experience_size=100",
+                                 "use_discount=true"]), Env())
+    assert [n for n, _ in agent.discount_model.named_parameters()] == [n for n, _ in synth.param_shapes(d)["discount_model"]]
+    assert agent.engine.groups["model"].specs[-1][0] == "discount_model"
+    rep = synth.make_replay(d, rows=100, seed=2)
+    for k, v in rep.items():
+        getattr(agent.buffer, k)[:] = v
+    agent.buffer.idx, agent.buffer.full = 0, True
+    np.random.seed(0)
+    logs = agent.train_step()
+    assert "discount_loss" in set(logs.keys()) and all(np.isfinite(float(v)) for v in logs.values())
+    assert 0.0 < float(logs["discount_loss"]) < 5.0
