@@ -24,7 +24,6 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define BD_WAVES 4
 #endif
 constexpr int kWaves = BD_WAVES;   // waves per workgroup (BD_WAVES/4 per SIMD)
-constexpr int kNI = 2;             // (legacy template argument; the block loop keeps up to two column blocks in flight)
 constexpr int kThreads = kWaves * 64;
 constexpr int kFragFloats = 256;   // floats per [16 rows x 16 k] fragment block
 
@@ -430,7 +429,7 @@ __device__ __forceinline__ void tile_linear_g(const Seg (&seg)[NSEG], const floa
 }
 
 // single-segment convenience forms
-template <int RT, int NI_UNUSED, class Epi>
+template <int RT, class Epi>
 __device__ __forceinline__ void tile_linear(const float* __restrict__ X, int Kb, const float* __restrict__ Wp,
                                             const float* __restrict__ bias, int N, Epi&& epi,
                                             float* __restrict__ scratch = nullptr) {
@@ -438,7 +437,7 @@ __device__ __forceinline__ void tile_linear(const float* __restrict__ X, int Kb,
     tile_linear_g<RT, 1>(seg, bias, N, epi, scratch);
 }
 
-template <int NI_UNUSED, int NSEG, class Epi>
+template <int NSEG, class Epi>
 __device__ __forceinline__ void tile_linear_seg(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
                                                 Epi&& epi, float* __restrict__ scratch = nullptr) {
     tile_linear_g<1, NSEG>(seg, bias, N, [&](int, int nb, floatx4 acc) { epi(nb, acc); }, scratch);

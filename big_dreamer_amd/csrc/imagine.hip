@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         // ---- actor hidden layers ----
         {
             const Seg segs[2] = {{h_cur, a.w_a0h, d.Kb_h}, {sf, a.w_a0s, d.Kb_s}};
-            tile_linear_seg<kNI, 2>(segs, a.b_a[0], a.Hd, hidden_epi(bufA, a.sv_actor, tn, a.Hd));
+            tile_linear_seg<2>(segs, a.b_a[0], a.Hd, hidden_epi(bufA, a.sv_actor, tn, a.Hd));
         }
         BD_STAMP(1);
         lds_barrier();
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
             float* dst = bufB;
             for (int l = 1; l < 4; ++l) {
                 const Seg segs[1] = {{src, a.w_a[l - 1], d.Kb_hd}};
-                tile_linear_seg<kNI, 1>(segs, a.b_a[l], a.Hd,
+                tile_linear_seg<1>(segs, a.b_a[l], a.Hd,
                                       hidden_epi(dst, a.sv_actor ? a.sv_actor + l * act_stride : nullptr, tn, a.Hd));
                 lds_barrier();
                 float* tmp = src; src = dst; dst = tmp;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         // ---- embed ----
         {
             const Seg segs[2] = {{sf, a.w_embed_s, d.Kb_s}, {af, a.w_embed_a, d.Kb_a}};
-            tile_linear_seg<kNI, 2>(segs, a.b_embed, a.Be, hidden_epi(xf, a.sv_x, tn, a.Be));
+            tile_linear_seg<2>(segs, a.b_embed, a.Be, hidden_epi(xf, a.sv_x, tn, a.Be));
         }
         BD_STAMP(7);
         lds_barrier();
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         // ---- prior ----
         {
             const Seg segs[1] = {{h_nxt, a.w_p1, d.Kb_h}};
-            tile_linear_seg<kNI, 1>(segs, a.b_p1, a.Hd, hidden_epi(bufA, a.sv_p, tn, a.Hd));
+            tile_linear_seg<1>(segs, a.b_p1, a.Hd, hidden_epi(bufA, a.sv_p, tn, a.Hd));
         }
         BD_STAMP(11);
         lds_barrier();
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
             });
         lds_barrier();
         // ---- 5: embed layer -> d state_t (carry) and d action_t -> actor output gradients ----
-        tile_linear<1, kNI>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
+        tile_linear<1>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -14,7 +14,7 @@ bool chain_ws_backward_ok(const bd_mlp_bwd_args* a);
 int chain_ws_backward(const bd_mlp_bwd_args* a, hipStream_t s);
 
 // ---- forward --------------------------------------------------------------------------------------
-template <int RT, int NI>
+template <int RT>
 __global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, int KbA, int KbB) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, in
         const bool last = (l == a.n_layers - 1);
         const int Kb = cdiv(L.K, 16), Nb = cdiv(L.N, 16);
         const bool gather0 = l == 0 && a.gD > 0;
-        tile_linear<RT, NI>(cur, Kb, L.w, L.bias, L.N, [&](int rt, int nb, floatx4 acc) {
+        tile_linear<RT>(cur, Kb, L.w, L.bias, L.N, [&](int rt, int nb, floatx4 acc) {
             const int c = lane & 15, col = nb * 16 + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, in
 }
 
 // ---- backward (dgrad chain) -------------------------------------------------------------------------
-template <int RT, int NI>
+template <int RT>
 __global__ __launch_bounds__(kThreads) void mlp_bwd_kernel(bd_mlp_bwd_args a, int KbA, int KbB) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_kernel(bd_mlp_bwd_args a, in
     }
     if (a.din0 != nullptr || a.din1 != nullptr) {
         const bd_layer_bwd L = a.layer[0];
-        tile_linear<RT, NI>(cur, cdiv(L.N, 16), L.wt, nullptr, L.K, [&](int rt, int nb, floatx4 acc) {
+        tile_linear<RT>(cur, cdiv(L.N, 16), L.wt, nullptr, L.K, [&](int rt, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -200,8 +200,8 @@ int bd_mlp_forward(const bd_mlp_fwd_args* a, void* stream) {
     }
     const int rt = pick_rt(a->M, KbA, KbB, xs);
     if (rt == 2)
-        return launch_chain(mlp_fwd_kernel<2, 2>, "bd_mlp_forward", a->M, 2, KbA, KbB, (hipStream_t)stream, *a, 2 * xs);
-    return launch_chain(mlp_fwd_kernel<1, 4>, "bd_mlp_forward", a->M, 1, KbA, KbB, (hipStream_t)stream, *a, xs);
+        return launch_chain(mlp_fwd_kernel<2>, "bd_mlp_forward", a->M, 2, KbA, KbB, (hipStream_t)stream, *a, 2 * xs);
+    return launch_chain(mlp_fwd_kernel<1>, "bd_mlp_forward", a->M, 1, KbA, KbB, (hipStream_t)stream, *a, xs);
 }
 
 int bd_mlp_backward(const bd_mlp_bwd_args* a, void* stream) {
@@ -223,8 +223,8 @@ int bd_mlp_backward(const bd_mlp_bwd_args* a, void* stream) {
     if (want_din) BD_REQUIRE(a->w0 + a->w1 == a->layer[0].K, "bd_mlp_backward: din widths != K of layer 0");
     if (chain_ws_backward_ok(a)) return chain_ws_backward(a, (hipStream_t)stream);
     const int rt = pick_rt(a->M, KbA, KbB);
-    if (rt == 2) return launch_chain(mlp_bwd_kernel<2, 2>, "bd_mlp_backward", a->M, 2, KbA, KbB, (hipStream_t)stream, *a);
-    return launch_chain(mlp_bwd_kernel<1, 4>, "bd_mlp_backward", a->M, 1, KbA, KbB, (hipStream_t)stream, *a);
+    if (rt == 2) return launch_chain(mlp_bwd_kernel<2>, "bd_mlp_backward", a->M, 2, KbA, KbB, (hipStream_t)stream, *a);
+    return launch_chain(mlp_bwd_kernel<1>, "bd_mlp_backward", a->M, 1, KbA, KbB, (hipStream_t)stream, *a);
 }
 
 }  // extern "C"

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kThreads) void observe_fwd_kernel(bd_observe_fwd_ar
         // ---- B: x = ELU(W_e [s~; a] + b_e) ----
         {
             const Seg segs[2] = {{sf, a.w_embed_s, d.Kb_s}, {af, a.w_embed_a, d.Kb_a}};
-            tile_linear_seg<kNI, 2>(segs, a.b_embed, a.Be, [&](int nb, floatx4 acc) {
+            tile_linear_seg<2>(segs, a.b_embed, a.Be, [&](int nb, floatx4 acc) {
                 const int col = nb * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kThreads) void observe_fwd_kernel(bd_observe_fwd_ar
         });
         lds_barrier();
         // ---- D: posterior hidden ----
-        tile_linear<1, kNI>(h_nxt, d.Kb_h, a.w_q1h, a.b_q1, a.Hd, [&](int, int nb, floatx4 acc) {
+        tile_linear<1>(h_nxt, d.Kb_h, a.w_q1h, a.b_q1, a.Hd, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kThreads) void observe_bwd_kernel(bd_observe_bwd_ar
         // ---- 2: d q (posterior hidden) ----
         {
             const Seg segs[2] = {{dM, a.wt_q2m, d.Kb_s}, {dRaw, a.wt_q2s, d.Kb_s}};
-            tile_linear_seg<kNI, 2>(segs, nullptr, a.Hd, [&](int nb, floatx4 acc) {
+            tile_linear_seg<2>(segs, nullptr, a.Hd, [&](int nb, floatx4 acc) {
                 const int col = nb * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void observe_bwd_kernel(bd_observe_bwd_ar
         }
         lds_barrier();
         // ---- 3: total d belief_{t+1}, GRU gate gradients ----
-        tile_linear<1, kNI>(dQ, d.Kb_hd, a.wt_q1h, nullptr, a.Be, [&](int, int nb, floatx4 acc) {
+        tile_linear<1>(dQ, d.Kb_hd, a.wt_q1h, nullptr, a.Be, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void observe_bwd_kernel(bd_observe_bwd_ar
             });
         lds_barrier();
         // ---- 5: d posterior_state_t through the embed layer and the nonterminal mask ----
-        tile_linear<1, kNI>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
+        tile_linear<1>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
         // ---- B: embed (every member, full width) ----
         {
             const Seg segs[2] = {{sf, a.w_embed_s, d.Kb_s}, {af, a.w_embed_a, d.Kb_a}};
-            tile_linear_seg<kNI, 2>(segs, a.b_embed, a.Be, [&](int nb, floatx4 acc) {
+            tile_linear_seg<2>(segs, a.b_embed, a.Be, [&](int nb, floatx4 acc) {
                 const int col = nb * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
         gather_payload(xbuf + (size_t)(epoch & 1) * (2 * nh), dhc, 2 * nh);
         lds_barrier();
         // ---- 5: d posterior_state_t through the embed layer and the nonterminal mask (every member) ----
-        tile_linear<1, kNI>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
+        tile_linear<1>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kThreads) void plan_rollout_kernel(bd_plan_args a) 
         // ---- x = ELU(W_e [s; a] + b_e) ----
         {
             const Seg segs[2] = {{sf, a.w_embed_s, d.Kb_s}, {af, a.w_embed_a, d.Kb_a}};
-            tile_linear_seg<kNI, 2>(segs, a.b_embed, a.Be, [&](int nb, floatx4 acc) {
+            tile_linear_seg<2>(segs, a.b_embed, a.Be, [&](int nb, floatx4 acc) {
                 const int col = nb * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kThreads) void plan_rollout_kernel(bd_plan_args a) 
         // ---- prior: s' = mean + std * eps ----
         {
             const Seg segs[1] = {{h_nxt, a.w_p1, d.Kb_h}};
-            tile_linear_seg<kNI, 1>(segs, a.b_p1, a.Hd, [&](int nb, floatx4 acc) {
+            tile_linear_seg<1>(segs, a.b_p1, a.Hd, [&](int nb, floatx4 acc) {
                 const int col = nb * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void plan_rollout_kernel(bd_plan_args a) 
         // ---- reward model on [h'; s'] (skipped when the host runs it batched over all H steps: a.returns == null) ----
         if (a.returns) {
             const Seg s0[1] = {{ff, a.w_r[0], d.Kb_f}};
-            tile_linear_seg<kNI, 1>(s0, a.b_r[0], a.Hd, [&](int nb, floatx4 acc) {
+            tile_linear_seg<1>(s0, a.b_r[0], a.Hd, [&](int nb, floatx4 acc) {
                 const int col = nb * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bufA[acc_frag_off(nb, lane, r)] = col < a.Hd ? elu(acc[r]) : 0.f;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void plan_rollout_kernel(bd_plan_args a) 
 #pragma unroll
             for (int l = 1; l < 4; ++l) {
                 const Seg sl[1] = {{src, a.w_r[l], d.Kb_hd}};
-                tile_linear_seg<kNI, 1>(sl, a.b_r[l], a.Hd, [&](int nb, floatx4 acc) {
+                tile_linear_seg<1>(sl, a.b_r[l], a.Hd, [&](int nb, floatx4 acc) {
                     const int col = nb * 16 + (lane & 15);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dst[acc_frag_off(nb, lane, r)] = col < a.Hd ? elu(acc[r]) : 0.f;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kThreads) void plan_rollout_kernel(bd_plan_args a) 
                 float* tmp = src; src = dst; dst = tmp;
             }
             const Seg so[1] = {{src, a.w_r[4], d.Kb_hd}};
-            tile_linear_seg<kNI, 1>(so, a.b_r[4], 1, [&](int nb, floatx4 acc) {
+            tile_linear_seg<1>(so, a.b_r[4], 1, [&](int nb, floatx4 acc) {
                 if (nb == 0 && (lane & 15) == 0) {       // column 0: one lane per group of four rows
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ret_s[4 * (lane >> 4) + r] += acc[r];      // sum over the horizon (:72)

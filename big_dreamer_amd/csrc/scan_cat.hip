@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
         // ---- B: x = ELU(W_es s~ + W_ea a + b_e) ----
         {
             const Seg segs[1] = {{af, a.w_embed_a, Kb_a}};
-            tile_linear_seg<kNI, 1>(segs, a.b_embed, a.Be, [&](int nb, floatx4 acc) {
+            tile_linear_seg<1>(segs, a.b_embed, a.Be, [&](int nb, floatx4 acc) {
                 const int col = nb * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
         lds_barrier();
         CAT_STAMP(5);
         // ---- D: posterior hidden ----
-        tile_linear<1, kNI>(h_nxt, Kb_h, a.w_q1h, a.b_q1, a.Hd, [&](int, int nb, floatx4 acc) {
+        tile_linear<1>(h_nxt, Kb_h, a.w_q1h, a.b_q1, a.Hd, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_bwd_kernel(bd_observe_ca
         lds_barrier();
         CAT_STAMP(19);
         // ---- 3: total d belief_{t+1}, GRU gate gradients ----
-        tile_linear<1, kNI>(dQ, Kb_hd, a.wt_q1h, nullptr, a.Be, [&](int, int nb, floatx4 acc) {
+        tile_linear<1>(dQ, Kb_hd, a.wt_q1h, nullptr, a.Be, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
         lds_barrier();
         {
             const Seg segs[1] = {{h_cur, a.w_a0h, Kb_h}};
-            tile_linear_seg<kNI, 1>(segs, a.b_a[0], a.Hd, [&](int nb, floatx4 acc) {
+            tile_linear_seg<1>(segs, a.b_a[0], a.Hd, [&](int nb, floatx4 acc) {
                 const int col = nb * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
             float* dst = bufB;
             for (int l = 1; l < 4; ++l) {
                 const Seg segs[1] = {{src, a.w_a[l - 1], Kb_hd}};
-                tile_linear_seg<kNI, 1>(segs, a.b_a[l], a.Hd,
+                tile_linear_seg<1>(segs, a.b_a[l], a.Hd,
                                       hidden_epi(dst, a.sv_actor ? a.sv_actor + l * act_stride : nullptr, tn, a.Hd));
                 lds_barrier();
                 float* tmp = src; src = dst; dst = tmp;
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
         // ---- embed ----
         {
             const Seg segs[1] = {{af, a.w_embed_a, Kb_a}};
-            tile_linear_seg<kNI, 1>(segs, a.b_embed, a.Be, [&](int nb, floatx4 acc) {
+            tile_linear_seg<1>(segs, a.b_embed, a.Be, [&](int nb, floatx4 acc) {
                 const int col = nb * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
         // ---- prior hidden, logits, sample ----
         {
             const Seg segs[1] = {{h_nxt, a.w_p1, Kb_h}};
-            tile_linear_seg<kNI, 1>(segs, a.b_p1, a.Hd, hidden_epi(bufA, a.sv_p, tn, a.Hd));
+            tile_linear_seg<1>(segs, a.b_p1, a.Hd, hidden_epi(bufA, a.sv_p, tn, a.Hd));
         }
         lds_barrier();
         cat_head_forward_full(gf, bufA, Kb_hd, a.w_p2, a.b_p2, a.q_prior + (tn + row0) * S, a.prior_logits + (tn + row0) * S,
