@@ -141,6 +141,46 @@ __device__ __forceinline__ void load_tile_concat(float* __restrict__ X, int Kb, 
     }
 }
 
+// The same for the tall chain kernels, two floats per lane: wave w takes rows w, w+kWaves, ..., a lane the column
+// pairs 2*lane, 2*lane+128, ...; all of a batch of rows is requested before the first LDS write.  Needs even w0 / ld0 /
+// ld1 and 8-byte aligned bases (checked by the caller: tile_pairs_ok); an odd last column is read alone.
+__host__ __device__ __forceinline__ bool tile_pairs_ok(const float* in0, int ld0, int w0, const float* in1, int ld1) {
+    return ((w0 | ld0) & 1) == 0 && ((uintptr_t)in0 & 7) == 0 && (in1 == nullptr || ((ld1 & 1) == 0 && ((uintptr_t)in1 & 7) == 0));
+}
+template <int RT>
+__device__ __forceinline__ void load_tile_concat_pairs(float* __restrict__ X, int Kb, int row0, int M,
+                                                       const float* __restrict__ in0, int ld0, int w0,
+                                                       const float* __restrict__ in1, int ld1, int w1) {
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    const int tid = bd_tid(), wave = tid >> 6, lane = tid & 63;
+    const int Kp = Kb * 16, W = w0 + w1;
+    constexpr int kRows = 16 * RT / kWaves;     // rows per wave
+    constexpr int kBatch = 6;
+    static_assert(16 * RT % kWaves == 0, "rows must divide over the waves");
+    for (int k = 2 * lane; k < Kp; k += 128) {
+#pragma unroll
+        for (int b0 = 0; b0 < kRows; b0 += kBatch) {
+            floatx2 v[kBatch];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+                const int r = wave + (b0 + b) * kWaves, grow = row0 + r;
+                v[b] = floatx2{0.f, 0.f};
+                if (b0 + b < kRows && grow < M) {
+                    if (k < w0) v[b] = *reinterpret_cast<const floatx2*>(in0 + (size_t)grow * ld0 + k);
+                    else if (k + 1 < W) v[b] = *reinterpret_cast<const floatx2*>(in1 + (size_t)grow * ld1 + (k - w0));
+                    else if (k < W) v[b][0] = in1[(size_t)grow * ld1 + (k - w0)];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+                const int r = wave + (b0 + b) * kWaves;
+                if (b0 + b < kRows)
+                    *reinterpret_cast<floatx2*>(X + (r >> 4) * Kb * kFragFloats + frag_idx(r & 15, k)) = v[b];
+            }
+        }
+    }
+}
+
 // ---- software-pipelined block loop ------------------------------------------------------------------
 // load(kb) returns the fragments of block kb (global weight float4s + LDS activation float4s); mma(frag)
 // consumes them.  Two register sets of D blocks each: while the MFMAs consume set A, the loads of the next D
@@ -441,6 +481,148 @@ template <int NSEG, class Epi>
 __device__ __forceinline__ void tile_linear_seg(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
                                                 Epi&& epi, float* __restrict__ scratch = nullptr) {
     tile_linear_g<1, NSEG>(seg, bias, N, [&](int, int nb, floatx4 acc) { epi(nb, acc); }, scratch);
+}
+
+// ---- tall workgroups: RT row tiles, balanced (row tile, column block) pairs, epilogue deferred -----------------
+// A 200-wide layer has 13 column blocks; handing whole blocks to 4 waves gives 4+3+3+3, i.e. the matrix pipe of three
+// SIMDs idles for a quarter of every sweep.  With RT row tiles per workgroup the unit of work is the (row tile, block)
+// pair: every wave takes the blocks wave, wave+4, ... of ALL row tiles (`per` = Nb / kWaves of them: one weight
+// fragment feeds RT MFMAs, one activation fragment feeds `per`), and the RT pairs of each leftover block go round-robin
+// over the waves, one at most per wave (13 blocks, RT = 3: 9 + 1 pairs on three waves, 9 on the fourth).
+// The accumulators stay in registers across a workgroup barrier (TallAcc) so the layer's output can overwrite its
+// input in LDS: one image per workgroup instead of two, which is what lets three 48-row workgroups share a CU.
+constexpr int kTallMaxPer = 3;    // column blocks per wave in the main part (N <= 15 blocks + leftover rule, host-checked)
+
+template <int RT>
+struct TallAcc {
+    floatx4 main[kTallMaxPer][RT];
+    floatx4 left;
+};
+
+__host__ __device__ __forceinline__ bool tall_shape_ok(int N, int RT) {
+    const int Nb = (N + 15) >> 4, per = Nb / kWaves;
+    return per <= kTallMaxPer && (Nb - per * kWaves) * RT <= kWaves;
+}
+
+template <int NSEG, int RT, int NI, int D>
+__device__ __forceinline__ void linear_sweep(const Seg (&seg)[NSEG], int nb0, floatx4 (*acc)[RT]) {
+    const int lane = bd_tid() & 63;
+    constexpr bool kSplit = (NI * RT == 1);
+    floatx4 acc2 = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        const int Kb = seg[s].Kb;
+        const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(seg[s].X) + lane;
+        const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(seg[s].W) + lane + (size_t)nb0 * Kb * 64;
+        const size_t wstride = (size_t)kWaves * Kb * 64;
+        pipelined_k<D>(
+            Kb,
+            [&](int kb) {
+                LinFrag<RT, NI> f;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) f.b[i] = W4[i * wstride + (size_t)kb * 64];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) f.a[rt] = X4[(rt * Kb + kb) * 64];
+                return f;
+            },
+            [&](const LinFrag<RT, NI>& f) {
+                if constexpr (kSplit) {
+                    acc[0][0] = mfma16(f.a[0][0], f.b[0][0], acc[0][0]);
+                    acc2 = mfma16(f.a[0][1], f.b[0][1], acc2);
+                    acc[0][0] = mfma16(f.a[0][2], f.b[0][2], acc[0][0]);
+                    acc2 = mfma16(f.a[0][3], f.b[0][3], acc2);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < NI; ++i)
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) acc[i][rt] = mfma16(f.a[rt][j], f.b[i][j], acc[i][rt]);
+                }
+            });
+    }
+    if constexpr (kSplit) acc[0][0] += acc2;
+}
+
+// pair owned by this wave among the leftover blocks: returns false when it has none
+__device__ __forceinline__ bool tall_left_pair(int Nb, int RT, int wave, int& rt, int& nb) {
+    const int per = Nb / kWaves, nleft = (Nb - per * kWaves) * RT;
+    if (wave >= nleft) return false;
+    const int lb = wave / RT;
+    rt = wave - lb * RT;
+    nb = per * kWaves + lb;
+    return true;
+}
+
+template <int RT, int NSEG>
+__device__ __forceinline__ void tall_sweep(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, TallAcc<RT>& t) {
+    const int lane = bd_tid() & 63, wave = bd_wave(bd_tid());
+    const int Nb = (N + 15) >> 4, per = Nb / kWaves;
+#pragma unroll
+    for (int i = 0; i < kTallMaxPer; ++i) {
+        const int col = (wave + i * kWaves) * 16 + (lane & 15);
+        const float b = (bias != nullptr && i < per && col < N) ? bias[col] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) t.main[i][rt] = floatx4{b, b, b, b};
+    }
+    if (per == 3) linear_sweep<NSEG, RT, 3, 1>(seg, wave, t.main);
+    else if (per == 2) linear_sweep<NSEG, RT, 2, 1>(seg, wave, t.main);
+    else if (per == 1) linear_sweep<NSEG, RT, 1, 2>(seg, wave, t.main);
+    int lrt = 0, lnb = 0;
+    if (tall_left_pair(Nb, RT, wave, lrt, lnb)) {
+        const int col = lnb * 16 + (lane & 15);
+        const float b = (bias != nullptr && col < N) ? bias[col] : 0.f;
+        floatx4 one[1][1] = {{floatx4{b, b, b, b}}};
+        Seg s1[NSEG];
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) s1[s] = Seg{seg[s].X + (size_t)lrt * seg[s].Kb * kFragFloats, seg[s].W, seg[s].Kb};
+        linear_sweep<NSEG, 1, 1, 2>(s1, lnb, one);
+        t.left = one[0][0];
+    }
+}
+
+// f(rt, nb, acc) for every pair this wave holds
+template <int RT, class F>
+__device__ __forceinline__ void tall_foreach(int N, const TallAcc<RT>& t, F&& f) {
+    const int wave = bd_wave(bd_tid());
+    const int Nb = (N + 15) >> 4, per = Nb / kWaves;
+#pragma unroll
+    for (int i = 0; i < kTallMaxPer; ++i)
+        if (i < per) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) f(rt, wave + i * kWaves, t.main[i][rt]);
+        }
+    int lrt = 0, lnb = 0;
+    if (tall_left_pair(Nb, RT, wave, lrt, lnb)) f(lrt, lnb, t.left);
+}
+
+// t[pair] = g(rt, nb) for every pair this wave holds (epilogue operands fetched ahead of a barrier)
+template <int RT, class G>
+__device__ __forceinline__ void tall_fill(int N, TallAcc<RT>& t, G&& g) {
+    const int wave = bd_wave(bd_tid());
+    const int Nb = (N + 15) >> 4, per = Nb / kWaves;
+#pragma unroll
+    for (int i = 0; i < kTallMaxPer; ++i)
+        if (i < per) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) t.main[i][rt] = g(rt, wave + i * kWaves);
+        }
+    int lrt = 0, lnb = 0;
+    if (tall_left_pair(Nb, RT, wave, lrt, lnb)) t.left = g(lrt, lnb);
+}
+
+template <int RT, class F>
+__device__ __forceinline__ void tall_foreach2(int N, const TallAcc<RT>& t, const TallAcc<RT>& u, F&& f) {
+    const int wave = bd_wave(bd_tid());
+    const int Nb = (N + 15) >> 4, per = Nb / kWaves;
+#pragma unroll
+    for (int i = 0; i < kTallMaxPer; ++i)
+        if (i < per) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) f(rt, wave + i * kWaves, t.main[i][rt], u.main[i][rt]);
+        }
+    int lrt = 0, lnb = 0;
+    if (tall_left_pair(Nb, RT, wave, lrt, lnb)) f(lrt, lnb, t.left, u.left);
 }
 
 // Two outputs sharing one column index (mean / raw-std rows of a Gaussian head): out0 = sum_s X_s W0_s^T + bias0,

@@ -151,6 +151,220 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_kernel(bd_mlp_bwd_args a, in
     }
 }
 
+#ifdef BD_STAMPS
+__device__ unsigned long long g_tallstamps[64];
+#define TALL_STAMP(slot)                                                                                         \
+    do {                                                                                                         \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && (slot) < 64) g_tallstamps[slot] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define TALL_STAMP(slot)
+#endif
+
+// ---- tall form: 16*RT rows per workgroup, ONE in-place LDS image, balanced pairs (bd_device.h: tall_sweep) ----------
+// For chains over tens of thousands of rows (the reward / value heads over every imagined transition).  Per layer:
+// sweep (accumulators stay in registers) -> barrier -> epilogue overwrites the image -> barrier.
+// Epilogue addressing is 32-bit (element offsets below 2^31, host-checked) off uniform base pointers, and a pair whose
+// 16 rows x 16 columns are all inside the matrix takes a branch-free path: with the general per-element form (64-bit
+// index products, a row and a column predicate and two optional outputs per value) the epilogue of a 200-wide layer cost
+// 10k cycles per wave against 20k for its sweep (s_memtime stamps, tools/tall_stamps.py).
+template <int RT>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void mlp_fwd_tall_kernel(bd_mlp_fwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int row0 = blockIdx.x * 16 * RT;
+    float* img = smem;
+    TALL_STAMP(0);
+    if (tile_pairs_ok(a.in0, a.ld0, a.w0, a.w1 ? a.in1 : nullptr, a.ld1))
+        load_tile_concat_pairs<RT>(img, cdiv(a.w0 + a.w1, 16), row0, a.M, a.in0, a.ld0, a.w0, a.in1, a.ld1, a.w1);
+    else
+        load_tile_concat<RT>(img, cdiv(a.w0 + a.w1, 16), row0, a.M, a.in0, a.ld0, a.w0, a.in1, a.ld1, a.w1);
+    TALL_STAMP(1);
+    lds_barrier();
+    TALL_STAMP(2);
+    const bool rows_full = row0 + 16 * RT <= a.M;      // workgroup-uniform
+    for (int l = 0; l < a.n_layers; ++l) {
+        const bd_layer L = a.layer[l];
+        const bool last = (l == a.n_layers - 1);
+        const int Kb = cdiv(L.K, 16), Nb = cdiv(L.N, 16);
+        const Seg seg[1] = {{img, L.w, Kb}};
+        TallAcc<RT> t;
+        tall_sweep<RT, 1>(seg, L.bias, L.N, t);
+        TALL_STAMP(3 + 4 * l);
+        if (!last) lds_barrier();            // every wave has read the layer's input
+        TALL_STAMP(4 + 4 * l);
+        const int lane = bd_tid() & 63, c = lane & 15, q = lane >> 4;
+        const int lds_lane = ((c >> 2) * 16 + 4 * q) * 4 + (c & 3);        // float index in a fragment block, r = 0
+        const unsigned g_lane = (unsigned)(row0 + 4 * q) * (unsigned)L.N + (unsigned)c;
+        const unsigned N = (unsigned)L.N;
+        tall_foreach<RT>(L.N, t, [&](int rt, int nb, floatx4 acc) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[r];
+            if (L.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = elu(v[r]);
+            }
+            if (!last) {
+                float* p = img + (rt * Nb + nb) * kFragFloats + lds_lane;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[4 * r] = v[r];
+            }
+            if (rows_full && nb * 16 + 16 <= L.N && !last) {      // uniform: the whole pair is inside the matrix
+                if (L.save) {
+                    float* __restrict__ s = L.save + (g_lane + (unsigned)(rt * 16) * N + (unsigned)(nb * 16));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[r * N] = v[r];
+                }
+            } else {
+                const int col = nb * 16 + c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int grow = row0 + rt * 16 + 4 * q + r;
+                    if (grow < a.M && col < L.N) {
+                        if (L.save) L.save[(unsigned)grow * N + (unsigned)col] = v[r];
+                        if (last) a.out[(unsigned)grow * (unsigned)a.ldo + (unsigned)col] = v[r];
+                    }
+                }
+            }
+        });
+        TALL_STAMP(5 + 4 * l);
+        if (!last) lds_barrier();
+        TALL_STAMP(6 + 4 * l);
+    }
+}
+
+template <int RT>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void mlp_bwd_tall_kernel(bd_mlp_bwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int row0 = blockIdx.x * 16 * RT;
+    float* img = smem;
+    {
+        const bd_layer_bwd L = a.layer[a.n_layers - 1];
+        const int Kb = cdiv(L.N, 16), Kp = Kb * 16;
+        for (int idx = threadIdx.x; idx < RT * 16 * Kp; idx += blockDim.x) {
+            const int r = idx / Kp, k = idx - r * Kp;
+            const int grow = row0 + r;
+            float v = 0.f;
+            if (grow < a.M && k < L.N) {
+                v = a.dout[(size_t)grow * a.lddo + k] * a.dout_scale;
+                if (L.act) v *= elu_grad_from_out(L.saved[(size_t)grow * L.N + k]);
+                if (L.dpre) L.dpre[(size_t)grow * L.N + k] = v;
+            }
+            img[(r >> 4) * Kb * kFragFloats + frag_idx(r & 15, k)] = v;
+        }
+    }
+    lds_barrier();
+    const bool rows_full = row0 + 16 * RT <= a.M;
+    for (int l = a.n_layers - 1; l >= 1; --l) {
+        const bd_layer_bwd L = a.layer[l];       // contraction over this layer's outputs (N) -> its inputs (K)
+        const bd_layer_bwd P = a.layer[l - 1];   // whose outputs those inputs are
+        const int Kb = cdiv(L.N, 16), Nb = cdiv(L.K, 16);
+        const Seg seg[1] = {{img, L.wt, Kb}};
+        TallAcc<RT> t;
+        tall_sweep<RT, 1>(seg, nullptr, L.K, t);
+        const int lane = bd_tid() & 63, c = lane & 15, q = lane >> 4;
+        const int lds_lane = ((c >> 2) * 16 + 4 * q) * 4 + (c & 3);
+        const unsigned N = (unsigned)P.N;
+        const unsigned g_lane = (unsigned)(row0 + 4 * q) * N + (unsigned)c;
+        // saved activations of the previous layer: requested before the barrier, consumed after it (out-of-range lanes
+        // read a clamped, valid address; their products are discarded below)
+        TallAcc<RT> sv;
+        tall_fill<RT>(L.K, sv, [&](int rt, int nb) {
+            floatx4 p = floatx4{1.f, 1.f, 1.f, 1.f};
+            if (P.act) {
+                if (rows_full && nb * 16 + 16 <= P.N) {
+                    const float* __restrict__ s = P.saved + (g_lane + (unsigned)(rt * 16) * N + (unsigned)(nb * 16));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[r] = s[r * N];
+                } else {
+                    const unsigned col = (unsigned)min(nb * 16 + c, P.N - 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        p[r] = P.saved[(unsigned)min(row0 + rt * 16 + 4 * q + r, a.M - 1) * N + col];
+                }
+            }
+            return p;
+        });
+        lds_barrier();
+        tall_foreach2<RT>(L.K, t, sv, [&](int rt, int nb, floatx4 acc, floatx4 p) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = P.act ? acc[r] * elu_grad_from_out(p[r]) : acc[r];
+            float* w = img + (rt * Nb + nb) * kFragFloats + lds_lane;
+            if (rows_full && nb * 16 + 16 <= P.N) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[4 * r] = v[r];
+                if (P.dpre) {
+                    float* __restrict__ s = P.dpre + (g_lane + (unsigned)(rt * 16) * N + (unsigned)(nb * 16));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[r * N] = v[r];
+                }
+            } else {
+                const int col = nb * 16 + c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int grow = row0 + rt * 16 + 4 * q + r;
+                    const bool in = grow < a.M && col < P.N;
+                    w[4 * r] = in ? v[r] : 0.f;
+                    if (in && P.dpre) P.dpre[(unsigned)grow * N + (unsigned)col] = v[r];
+                }
+            }
+        });
+        lds_barrier();
+    }
+    if (a.din0 != nullptr || a.din1 != nullptr) {
+        const bd_layer_bwd L = a.layer[0];
+        tile_linear<RT>(img, cdiv(L.N, 16), L.wt, nullptr, L.K, [&](int rt, int nb, floatx4 acc) {
+            const int ln = bd_tid() & 63;
+            const int col = nb * 16 + (ln & 15);
+            const unsigned r0 = (unsigned)(row0 + rt * 16 + 4 * (ln >> 4));
+            if (rows_full && a.din1 == nullptr && nb * 16 + 16 <= a.w0) {        // the common single-destination case
+                float* __restrict__ p = a.din0 + (r0 * (unsigned)a.ld0 + (unsigned)col);
+                if (a.accumulate) {
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = p[r * (unsigned)a.ld0];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[r * (unsigned)a.ld0] = o[r] + acc[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[r * (unsigned)a.ld0] = acc[r];
+                }
+                return;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int grow = (int)r0 + r;
+                if (grow >= a.M) continue;
+                float* p = nullptr;
+                if (col < a.w0) { if (a.din0) p = a.din0 + (size_t)grow * a.ld0 + col; }
+                else if (col < a.w0 + a.w1) { if (a.din1) p = a.din1 + (size_t)grow * a.ld1 + (col - a.w0); }
+                if (p) *p = a.accumulate ? *p + acc[r] : acc[r];
+            }
+        });
+    }
+}
+
+constexpr int kTallRT = 3;
+constexpr int kTallMinTiles = 512;   // below this the 16-row workgroups fill the chip better
+
+static int tall_mode = -1;   // -1: BD_MLP_TALL from the environment (unset = on), 0 / 1: forced (bd_mlp_set_tall),
+                             // 2: on for every M (diagnostics)
+
+static bool tall_enabled() {
+    if (tall_mode >= 0) return tall_mode != 0;
+    static const char* e = getenv("BD_MLP_TALL");
+    return !(e && atoi(e) == 0);
+}
+
+template <class K, class Args>
+static int launch_tall(K kernel, const char* name, int M, int KbMax, hipStream_t s, const Args& args) {
+    const size_t lds = (size_t)kTallRT * KbMax * kFragFloats * sizeof(float);
+    hipLaunchKernelGGL(kernel, dim3(cdiv(M, 16 * kTallRT)), dim3(kThreads), lds, s, args);
+    BD_CHECK_LAUNCH(name);
+    return 0;
+}
+
 template <class K, class Args>
 static int launch_chain(K kernel, const char* name, int M, int RT, int KbA, int KbB, hipStream_t s, const Args& args,
                         size_t extra_floats = 0) {
@@ -177,6 +391,17 @@ static int pick_rt(int M, int KbA, int KbB, size_t extra_per_rt = 0) {
 
 extern "C" {
 
+#ifdef BD_STAMPS
+int bd_debug_tallstamps(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(bd::g_tallstamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
+
+int bd_mlp_set_tall(int mode) {
+    bd::tall_mode = mode;
+    return 0;
+}
+
 int bd_mlp_forward(const bd_mlp_fwd_args* a, void* stream) {
     using namespace bd;
     BD_REQUIRE(a && a->M > 0 && a->n_layers >= 1 && a->n_layers <= BD_MAX_LAYERS, "bd_mlp_forward: bad M/n_layers");
@@ -192,6 +417,17 @@ int bd_mlp_forward(const bd_mlp_fwd_args* a, void* stream) {
         k = L.N;
     }
     if (chain_ws_forward_ok(a)) return chain_ws_forward(a, (hipStream_t)stream);
+    if (tall_enabled() && a->gD == 0 && cdiv(a->M, 16) >= (tall_mode == 2 ? 1 : kTallMinTiles)) {
+        bool ok = true;
+        size_t widest = (size_t)a->ldo;                            // 32-bit element offsets inside the kernel
+        for (int l = 0; l < a->n_layers; ++l) {
+            ok = ok && tall_shape_ok(a->layer[l].N, kTallRT);
+            widest = (size_t)a->layer[l].N > widest ? (size_t)a->layer[l].N : widest;
+        }
+        ok = ok && (size_t)a->M * widest < ((size_t)1 << 31);
+        if (ok) return launch_tall(mlp_fwd_tall_kernel<kTallRT>, "bd_mlp_forward(tall)", a->M, KbA > KbB ? KbA : KbB,
+                                   (hipStream_t)stream, *a);
+    }
     size_t xs = 0;
     if (a->gD > 0) {
         BD_REQUIRE(a->gidx && a->gWT && a->gC > 0 && a->gC <= 256 && a->layer[0].N % 4 == 0,
@@ -222,6 +458,18 @@ int bd_mlp_backward(const bd_mlp_bwd_args* a, void* stream) {
     }
     if (want_din) BD_REQUIRE(a->w0 + a->w1 == a->layer[0].K, "bd_mlp_backward: din widths != K of layer 0");
     if (chain_ws_backward_ok(a)) return chain_ws_backward(a, (hipStream_t)stream);
+    if (tall_enabled() && cdiv(a->M, 16) >= (tall_mode == 2 ? 1 : kTallMinTiles)) {
+        bool ok = true;
+        size_t widest = (size_t)(a->ld0 > a->ld1 ? a->ld0 : a->ld1);
+        for (int l = a->n_layers - 1; l >= 1; --l) {
+            ok = ok && tall_shape_ok(a->layer[l].K, kTallRT);
+            widest = (size_t)a->layer[l].K > widest ? (size_t)a->layer[l].K : widest;
+        }
+        ok = ok && (size_t)a->M * widest < ((size_t)1 << 31);
+        int kb = KbA > KbB ? KbA : KbB;
+        if (want_din) kb = cdiv(a->layer[0].N, 16) > kb ? cdiv(a->layer[0].N, 16) : kb;
+        if (ok) return launch_tall(mlp_bwd_tall_kernel<kTallRT>, "bd_mlp_backward(tall)", a->M, kb, (hipStream_t)stream, *a);
+    }
     const int rt = pick_rt(a->M, KbA, KbB);
     if (rt == 2) return launch_chain(mlp_bwd_kernel<2>, "bd_mlp_backward", a->M, 2, KbA, KbB, (hipStream_t)stream, *a);
     return launch_chain(mlp_bwd_kernel<1>, "bd_mlp_backward", a->M, 1, KbA, KbB, (hipStream_t)stream, *a);

@@ -101,6 +101,12 @@ int bd_mlp_backward(const bd_mlp_bwd_args* a, void* stream);
  * (BD_CHAIN_WS=1|2; unset = off: measured no faster inside the three-stream step). */
 int bd_chain_ws_set_mode(int mode);
 
+/* Tall form of the two chain entry points (csrc/mlp.hip, mlp_*_tall_kernel): for M >= 8192 rows and layer widths of at
+ * most 15 column blocks, 48-row workgroups with one in-place LDS image and (row tile, column block) pairs balanced over
+ * the four waves.  Same arguments, same results (summation order within a dot product is unchanged).  mode 1: on (the
+ * default), 0: always the 16/32-row form, -1: as the environment says (BD_MLP_TALL=0 switches it off). */
+int bd_mlp_set_tall(int mode);
+
 /* dW[N x K] (+)= dpre^T[N x M] * act[M x K],  db[N] (+)= column sums of dpre (db may be NULL).
  * Deterministic split-M (slabs in `ws`, then a fixed-order reduction); accumulate=1 adds to dW/db;
  * ws must hold bd_wgrad_ws_floats(M,N,K) floats (its capacity ws_floats is checked).
