@@ -51,6 +51,28 @@ __device__ __forceinline__ int bd_tid() {
 static_assert((kWaves & (kWaves - 1)) == 0, "kWaves must be a power of two");
 __device__ __forceinline__ int bd_wave(int tid) { return ((tid >> 6) + (int)blockIdx.x) & (kWaves - 1); }
 
+// Wave priority around non-MFMA sections.  A wave whose SIMD-mates stream MFMAs gets roughly one issue slot per MFMA of
+// theirs (32 cycles): a 300-instruction epilogue that takes 5.7k cycles alone took 16-33k next to two sweeping waves, the
+// four DMA instructions of a weight-gradient stage 1.2-1.5k (s_memtime stamps).  Raised priority lets the short
+// VALU / memory section through; the MFMA streams lose a few issue slots.  -DBD_NO_PRIO compiles them out.
+#ifdef BD_NO_PRIO
+#define BD_PRIO_HI()
+#define BD_PRIO_LO()
+#else
+#define BD_PRIO_HI() __builtin_amdgcn_s_setprio(3)
+#define BD_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#endif
+
+// Kernel arguments re-read from the kernarg segment.  The scan kernels take ~60 pointers: kept live across the time loop
+// they exceed the 102 SGPRs and hipcc spills them into VGPR lanes -- v_writelane / v_readlane were 1 600 of the 4 800
+// VALU instructions of the imagination forward kernel, executed on the SIMD that should be issuing MFMAs (fp32 MFMA and
+// VALU do not overlap on gfx950).  BD_KARGS(T) names the by-value argument block through a constant-address-space pointer
+// and BD_KARGS_FRESH() makes that pointer opaque again, so that each phase loads the few fields it uses with s_load
+// (scalar cache) instead of holding all of them.
+#define BD_KARGS(T, name) const __attribute__((address_space(4))) T* name = \
+    (const __attribute__((address_space(4))) T*)__builtin_amdgcn_kernarg_segment_ptr()
+#define BD_KARGS_FRESH(name) asm volatile("" : "+s"(name))
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc emit s_waitcnt vmcnt(0), and
 // on CDNA4 vmcnt counts global STORES too: every phase of a persistent kernel would wait for its
 // saved-activation stores to be acknowledged by L2.  The tile kernels hand data between phases through LDS
@@ -288,11 +310,25 @@ struct NoPre {
     __device__ __forceinline__ NoPreVal operator()(int, int) const { return NoPreVal{}; }
 };
 
+// Diagnostic build only (-DBD_STAMPS): s_memtime at points inside a tile primitive, recorded by thread 0 of workgroup 0
+// when the caller passes a slot base >= 0 (each translation unit has its own table).  Never in the shipped .so.
+#ifdef BD_STAMPS
+static __device__ unsigned long long g_dstamps[64];
+#define BD_DSTAMP(base, k)                                                                                  \
+    do {                                                                                                    \
+        if ((base) >= 0 && (base) + (k) < 64 && blockIdx.x == 0 && threadIdx.x == 0)                        \
+            g_dstamps[(base) + (k)] = __builtin_amdgcn_s_memtime();                                          \
+    } while (0)
+#else
+#define BD_DSTAMP(base, k)
+#endif
+
 // NI column blocks nb0, nb0+kWaves, ... of this wave (all valid), RT row tiles, all segments.
 template <int NSEG, int RT, int NI, int D, class Pre, class Epi>
 __device__ __forceinline__ void linear_blocks(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, int nb0,
-                                              Pre&& pre, Epi&& epi) {
+                                              Pre&& pre, Epi&& epi, int sb = -1) {
     const int lane = bd_tid() & 63;
+    BD_DSTAMP(sb, 0);
     decltype(pre(0, 0)) pf[NI][RT];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -308,6 +344,7 @@ __device__ __forceinline__ void linear_blocks(const Seg (&seg)[NSEG], const floa
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[i][rt] = floatx4{b, b, b, b};
     }
+    BD_DSTAMP(sb, 1);
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
         const int Kb = seg[s].Kb;
@@ -341,24 +378,14 @@ __device__ __forceinline__ void linear_blocks(const Seg (&seg)[NSEG], const floa
             });
     }
     if constexpr (kSplit) acc[0][0] += acc2;
+    BD_DSTAMP(sb, 2);
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) epi(rt, nb0 + i * kWaves, acc[i][rt], pf[i][rt]);
+    BD_DSTAMP(sb, 3);
 }
 
-// Diagnostic build only (-DBD_STAMPS): s_memtime at points inside a tile primitive, recorded by thread 0 of workgroup 0
-// when the caller passes a slot base >= 0 (each translation unit has its own table).  Never in the shipped .so.
-#ifdef BD_STAMPS
-static __device__ unsigned long long g_dstamps[64];
-#define BD_DSTAMP(base, k)                                                                                  \
-    do {                                                                                                    \
-        if ((base) >= 0 && (base) + (k) < 64 && blockIdx.x == 0 && threadIdx.x == 0)                        \
-            g_dstamps[(base) + (k)] = __builtin_amdgcn_s_memtime();                                          \
-    } while (0)
-#else
-#define BD_DSTAMP(base, k)
-#endif
 
 // ---- split-K over waves for narrow outputs ----------------------------------------------------------------
 // When a layer has at most two (column block, row tile) pairs (N <= 32: the mean/std heads, the N=1 heads of the
@@ -443,7 +470,7 @@ __device__ __forceinline__ void tile_linear_splitk(const Seg (&seg)[NSEG], const
 // epi(rt, nb, acc): lane holds out[row = 16*rt + 4*(lane>>4) + r][col = nb*16 + (lane&15)], r = 0..3.
 template <int RT, int NSEG, class Pre, class Epi>
 __device__ __forceinline__ void tile_linear_pre(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Pre&& pre,
-                                                Epi&& epi, float* __restrict__ scratch = nullptr) {
+                                                Epi&& epi, float* __restrict__ scratch = nullptr, int sb = -1) {
     const int wave = bd_wave(bd_tid());
     const int Nb = (N + 15) >> 4;
     if (scratch != nullptr && Nb * RT <= kSplitPairs) {   // workgroup-uniform
@@ -456,16 +483,16 @@ __device__ __forceinline__ void tile_linear_pre(const Seg (&seg)[NSEG], const fl
     constexpr int D = BD_PIPE_D;      // K blocks per register set of the software pipeline (two sets); measured on
                                       // MI355X after the kernels became spill-free: D = 3 / 4 are 4-6 % slower than 2
     for (int nb0 = wave; nb0 < Nb; nb0 += 2 * kWaves) {
-        if (nb0 + kWaves < Nb) linear_blocks<NSEG, RT, 2, D>(seg, bias, N, nb0, pre, epi);
-        else linear_blocks<NSEG, RT, 1, D>(seg, bias, N, nb0, pre, epi);
+        if (nb0 + kWaves < Nb) linear_blocks<NSEG, RT, 2, D>(seg, bias, N, nb0, pre, epi, sb);
+        else linear_blocks<NSEG, RT, 1, D>(seg, bias, N, nb0, pre, epi, sb);
     }
 }
 
 template <int RT, int NSEG, class Epi>
 __device__ __forceinline__ void tile_linear_g(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Epi&& epi,
-                                              float* __restrict__ scratch = nullptr) {
+                                              float* __restrict__ scratch = nullptr, int sb = -1) {
     tile_linear_pre<RT, NSEG>(seg, bias, N, NoPre{}, [&](int rt, int nb, floatx4 acc, NoPreVal) { epi(rt, nb, acc); },
-                              scratch);
+                              scratch, sb);
 }
 
 // single-segment convenience forms
@@ -479,8 +506,8 @@ __device__ __forceinline__ void tile_linear(const float* __restrict__ X, int Kb,
 
 template <int NSEG, class Epi>
 __device__ __forceinline__ void tile_linear_seg(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
-                                                Epi&& epi, float* __restrict__ scratch = nullptr) {
-    tile_linear_g<1, NSEG>(seg, bias, N, [&](int, int nb, floatx4 acc) { epi(nb, acc); }, scratch);
+                                                Epi&& epi, float* __restrict__ scratch = nullptr, int sb = -1) {
+    tile_linear_g<1, NSEG>(seg, bias, N, [&](int, int nb, floatx4 acc) { epi(nb, acc); }, scratch, sb);
 }
 
 // ---- tall workgroups: RT row tiles, balanced (row tile, column block) pairs, epilogue deferred -----------------
@@ -504,7 +531,13 @@ __host__ __device__ __forceinline__ bool tall_shape_ok(int N, int RT) {
     return per <= kTallMaxPer && (Nb - per * kWaves) * RT <= kWaves;
 }
 
-template <int NSEG, int RT, int NI, int D>
+// TR: the two MFMA operands change places, D^T = W X^T.  The registers are the same ones (a weight fragment is a valid A
+// operand, an activation fragment a valid B operand); what changes is the accumulator: lane holds
+// out[row = lane&15][col = nb*16 + 4*(lane>>4) + r], r = 0..3 -- four CONSECUTIVE columns of one row, which is exactly
+// one lane's 16 bytes of the next layer's fragment tile (frag[nb][lane][r]) and 16 contiguous bytes of a row-major
+// output.  The epilogue becomes one ds_write_b128 + one global_store_dwordx4 per block instead of four conflicting
+// ds_write_b32 + four dword stores.
+template <int NSEG, int RT, int NI, int D, bool TR = false>
 __device__ __forceinline__ void linear_sweep(const Seg (&seg)[NSEG], int nb0, floatx4 (*acc)[RT]) {
     const int lane = bd_tid() & 63;
     constexpr bool kSplit = (NI * RT == 1);
@@ -527,17 +560,25 @@ __device__ __forceinline__ void linear_sweep(const Seg (&seg)[NSEG], int nb0, fl
             },
             [&](const LinFrag<RT, NI>& f) {
                 if constexpr (kSplit) {
-                    acc[0][0] = mfma16(f.a[0][0], f.b[0][0], acc[0][0]);
-                    acc2 = mfma16(f.a[0][1], f.b[0][1], acc2);
-                    acc[0][0] = mfma16(f.a[0][2], f.b[0][2], acc[0][0]);
-                    acc2 = mfma16(f.a[0][3], f.b[0][3], acc2);
+                    if constexpr (TR) {
+                        acc[0][0] = mfma16(f.b[0][0], f.a[0][0], acc[0][0]);
+                        acc2 = mfma16(f.b[0][1], f.a[0][1], acc2);
+                        acc[0][0] = mfma16(f.b[0][2], f.a[0][2], acc[0][0]);
+                        acc2 = mfma16(f.b[0][3], f.a[0][3], acc2);
+                    } else {
+                        acc[0][0] = mfma16(f.a[0][0], f.b[0][0], acc[0][0]);
+                        acc2 = mfma16(f.a[0][1], f.b[0][1], acc2);
+                        acc[0][0] = mfma16(f.a[0][2], f.b[0][2], acc[0][0]);
+                        acc2 = mfma16(f.a[0][3], f.b[0][3], acc2);
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int i = 0; i < NI; ++i)
 #pragma unroll
-                            for (int rt = 0; rt < RT; ++rt) acc[i][rt] = mfma16(f.a[rt][j], f.b[i][j], acc[i][rt]);
+                            for (int rt = 0; rt < RT; ++rt)
+                                acc[i][rt] = TR ? mfma16(f.b[i][j], f.a[rt][j], acc[i][rt]) : mfma16(f.a[rt][j], f.b[i][j], acc[i][rt]);
                 }
             });
     }
@@ -554,29 +595,39 @@ __device__ __forceinline__ bool tall_left_pair(int Nb, int RT, int wave, int& rt
     return true;
 }
 
+// Accumulators in the transposed form (linear_sweep<..., TR = true>): lane holds row lane&15, columns
+// nb*16 + 4*(lane>>4) + r.  N % 4 == 0 (host-checked by the tall chain launchers); the bias vector sits at an arbitrary
+// float offset of the flat parameter buffer, so it is read with scalar loads.
+__device__ __forceinline__ floatx4 tall_bias(const float* __restrict__ bias, int N, int nb, int lane) {
+    const int col0 = nb * 16 + 4 * (lane >> 4);
+    floatx4 b = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr && col0 < N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r] = bias[col0 + r];
+    }
+    return b;
+}
+
 template <int RT, int NSEG>
 __device__ __forceinline__ void tall_sweep(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, TallAcc<RT>& t) {
     const int lane = bd_tid() & 63, wave = bd_wave(bd_tid());
     const int Nb = (N + 15) >> 4, per = Nb / kWaves;
 #pragma unroll
     for (int i = 0; i < kTallMaxPer; ++i) {
-        const int col = (wave + i * kWaves) * 16 + (lane & 15);
-        const float b = (bias != nullptr && i < per && col < N) ? bias[col] : 0.f;
+        const floatx4 b = i < per ? tall_bias(bias, N, wave + i * kWaves, lane) : floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) t.main[i][rt] = floatx4{b, b, b, b};
+        for (int rt = 0; rt < RT; ++rt) t.main[i][rt] = b;
     }
-    if (per == 3) linear_sweep<NSEG, RT, 3, 1>(seg, wave, t.main);
-    else if (per == 2) linear_sweep<NSEG, RT, 2, 1>(seg, wave, t.main);
-    else if (per == 1) linear_sweep<NSEG, RT, 1, 2>(seg, wave, t.main);
+    if (per == 3) linear_sweep<NSEG, RT, 3, 1, true>(seg, wave, t.main);
+    else if (per == 2) linear_sweep<NSEG, RT, 2, 1, true>(seg, wave, t.main);
+    else if (per == 1) linear_sweep<NSEG, RT, 1, 2, true>(seg, wave, t.main);
     int lrt = 0, lnb = 0;
     if (tall_left_pair(Nb, RT, wave, lrt, lnb)) {
-        const int col = lnb * 16 + (lane & 15);
-        const float b = (bias != nullptr && col < N) ? bias[col] : 0.f;
-        floatx4 one[1][1] = {{floatx4{b, b, b, b}}};
+        floatx4 one[1][1] = {{tall_bias(bias, N, lnb, lane)}};
         Seg s1[NSEG];
 #pragma unroll
         for (int s = 0; s < NSEG; ++s) s1[s] = Seg{seg[s].X + (size_t)lrt * seg[s].Kb * kFragFloats, seg[s].W, seg[s].Kb};
-        linear_sweep<NSEG, 1, 1, 2>(s1, lnb, one);
+        linear_sweep<NSEG, 1, 1, 2, true>(s1, lnb, one);
         t.left = one[0][0];
     }
 }

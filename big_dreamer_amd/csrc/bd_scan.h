@@ -37,6 +37,11 @@ __device__ __forceinline__ void entropy_sample(const EntConst& c, float e, float
     ds = diff * diff * c.inv_var * c.inv_sd - c.inv_sd + gx * J * e;
 }
 
+// The three epilogue helpers below take a branch-free path for a block that lies wholly inside the matrix (uniform
+// test: every row of the tile valid, all 16 columns < width) with 32-bit lane offsets off a uniform base pointer; the
+// per-element predicates and 64-bit index products of the general path cost ~250 cycles per value (s_memtime stamps of
+// the dense-chain kernels, tools/tall_stamps.py).  rows * width of one time slice must stay below 2^31 (host-checked).
+
 // hidden layer epilogue: ELU -> LDS fragment (+ optional save for the backward)
 struct HiddenEpi {
     float* dst;
@@ -44,13 +49,28 @@ struct HiddenEpi {
     size_t tn;
     int width, rows, row0, lane;
     __device__ __forceinline__ void operator()(int nb, floatx4 acc) const {
-        const int col = nb * 16 + (lane & 15);
+        const int c = lane & 15, q = lane >> 4;
+        float* __restrict__ p = dst + acc_frag_off(nb, lane, 0);
+        if (row0 + 16 <= rows && nb * 16 + 16 <= width) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = elu(acc[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[4 * r] = v[r];
+            if (save) {
+                float* __restrict__ s = save + tn * width + ((unsigned)(row0 + 4 * q) * (unsigned)width + (unsigned)(nb * 16 + c));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[(unsigned)r * (unsigned)width] = v[r];
+            }
+            return;
+        }
+        const int col = nb * 16 + c;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int grow = row0 + 4 * (lane >> 4) + r;
+            const int grow = row0 + 4 * q + r;
             const bool ok = grow < rows && col < width;
             const float v = ok ? elu(acc[r]) : 0.f;
-            dst[acc_frag_off(nb, lane, r)] = v;
+            p[4 * r] = v;
             if (ok && save) save[(tn + grow) * width + col] = v;
         }
     }
@@ -64,10 +84,27 @@ struct DpreEpi {
     size_t tn;
     int width, rows, row0, lane;
     __device__ __forceinline__ void operator()(int, int nb, floatx4 acc, const Pre4& p) const {
-        const int col = nb * 16 + (lane & 15);
+        const int c = lane & 15, q = lane >> 4;
+        if (row0 + 16 <= rows && nb * 16 + 16 <= width) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[r] * elu_grad_from_out(p.v[r]);
+            if (out) {
+                float* __restrict__ s = out + tn * width + ((unsigned)(row0 + 4 * q) * (unsigned)width + (unsigned)(nb * 16 + c));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[(unsigned)r * (unsigned)width] = v[r];
+            }
+            if (dst) {
+                float* __restrict__ w = dst + acc_frag_off(nb, lane, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[4 * r] = v[r];
+            }
+            return;
+        }
+        const int col = nb * 16 + c;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int grow = row0 + 4 * (lane >> 4) + r;
+            const int grow = row0 + 4 * q + r;
             float v = 0.f;
             if (grow < rows && col < width) {
                 v = acc[r] * elu_grad_from_out(p.v[r]);
@@ -84,10 +121,17 @@ struct DprePre {
     int width, rows, row0, lane;
     __device__ __forceinline__ Pre4 operator()(int, int nb) const {
         Pre4 p;
-        const int col = nb * 16 + (lane & 15);
+        const int c = lane & 15, q = lane >> 4;
+        if (row0 + 16 <= rows && nb * 16 + 16 <= width) {
+            const float* __restrict__ s = saved + tn * width + ((unsigned)(row0 + 4 * q) * (unsigned)width + (unsigned)(nb * 16 + c));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p.v[r] = s[(unsigned)r * (unsigned)width];
+            return p;
+        }
+        const int col = nb * 16 + c;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int grow = row0 + 4 * (lane >> 4) + r;
+            const int grow = row0 + 4 * q + r;
             p.v[r] = (grow < rows && col < width) ? saved[(tn + grow) * width + col] : 1.f;
         }
         return p;

@@ -39,8 +39,10 @@ struct ImgDims {
 };
 
 
-__global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_args a) {
+__global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_args a_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    BD_KARGS(bd_imagine_fwd_args, ap);
+#define a (*ap)
     const ImgDims d(a.Be, a.S, a.A, a.Hd);
     const int row0 = blockIdx.x * 16;
     const int F = a.Be + a.S, A = a.A;
@@ -63,7 +65,6 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
     for (int i = threadIdx.x; i < d.Kb_a * kFragFloats; i += blockDim.x) af[i] = 0.f;   // columns >= A stay zero
     lds_barrier();
 
-    const GruW gw{a.w_ir, a.w_iz, a.w_in, a.w_hr, a.w_hz, a.w_hn, a.b_ih, a.b_hh};
     const size_t act_stride = a.sv_actor_stride ? a.sv_actor_stride : (size_t)a.Hm * a.N * a.Hd;
     const float inv_ns = 1.f / (float)a.n_samples;
 
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
             return HiddenEpi{dst, save, tn_, width, a.N, row0, lane};
         };
         BD_STAMP(0);
+        BD_KARGS_FRESH(ap);
         // ---- actor hidden layers ----
         {
             const Seg segs[2] = {{h_cur, a.w_a0h, d.Kb_h}, {sf, a.w_a0s, d.Kb_s}};
@@ -84,19 +86,24 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         BD_STAMP(1);
         lds_barrier();
         BD_STAMP(2);
+        BD_KARGS_FRESH(ap);
         {
             float* src = bufA;
             float* dst = bufB;
             for (int l = 1; l < 4; ++l) {
                 const Seg segs[1] = {{src, a.w_a[l - 1], d.Kb_hd}};
                 tile_linear_seg<1>(segs, a.b_a[l], a.Hd,
-                                      hidden_epi(dst, a.sv_actor ? a.sv_actor + l * act_stride : nullptr, tn, a.Hd));
+                                      hidden_epi(dst, a.sv_actor ? a.sv_actor + l * act_stride : nullptr, tn, a.Hd), nullptr,
+                                      (t == 3 && l == 2) ? 32 : -1);
+                BD_DSTAMP((t == 3 && l == 2) ? 32 : -1, 4);
                 lds_barrier();
+                BD_DSTAMP((t == 3 && l == 2) ? 32 : -1, 5);
                 float* tmp = src; src = dst; dst = tmp;
             }
             // after 3 layers the activations of layer 3 are in bufB (A->B, B->A, A->B)
         }
         BD_STAMP(3);
+        BD_KARGS_FRESH(ap);
         // ---- actor output, action sample ----
         {
             const Seg2 segs[1] = {{bufB, a.w_a4m, a.w_a4s, d.Kb_hd}};
@@ -128,6 +135,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         BD_STAMP(4);
         lds_barrier();
         BD_STAMP(5);
+        BD_KARGS_FRESH(ap);
         // ---- entropy: n_samples draws per (row, action dim); thread = (row, sample lane) ----
         {
             const int row = tid & 15, sl = tid >> 4;   // 16 sample lanes
@@ -175,6 +183,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
             a.entropy[tn + row0 + tid] = -s * inv_ns;
         }
         BD_STAMP(6);
+        BD_KARGS_FRESH(ap);
         // ---- embed ----
         {
             const Seg segs[2] = {{sf, a.w_embed_s, d.Kb_s}, {af, a.w_embed_a, d.Kb_a}};
@@ -183,13 +192,43 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         BD_STAMP(7);
         lds_barrier();
         BD_STAMP(8);
+        BD_KARGS_FRESH(ap);
         // ---- GRU ----
+        const GruW gw{a.w_ir, a.w_iz, a.w_in, a.w_hr, a.w_hz, a.w_hn, a.b_ih, a.b_hh};
         gru_tile(xf, h_cur, d.Kb_h, a.Be, gw, [&](int nb, floatx4 R, floatx4 Z, floatx4 NI, floatx4 NH) {
-            const int col = nb * 16 + (lane & 15);
+            const int c = lane & 15, q = lane >> 4;
+            const int off0 = acc_frag_off(nb, lane, 0);
+            if (row0 + 16 <= a.N && nb * 16 + 16 <= a.Be) {      // uniform: block wholly inside the matrix
+                float rr[4], zz[4], nn[4], hn[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    rr[r] = sigmoidf(R[r]);
+                    zz[r] = sigmoidf(Z[r]);
+                    nn[r] = tanh_act(NI[r] + rr[r] * NH[r]);
+                    hn[r] = (1.f - zz[r]) * nn[r] + zz[r] * h_cur[off0 + 4 * r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h_nxt[off0 + 4 * r] = hn[r];
+                const unsigned lo = (unsigned)(row0 + 4 * q), cc = (unsigned)(nb * 16 + c);
+                float* __restrict__ f = a.feat + tn * F + (lo * (unsigned)F + cc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[(unsigned)r * (unsigned)F] = hn[r];
+                if (a.sv_gates) {
+                    const unsigned Be = (unsigned)a.Be;
+                    float* __restrict__ g = a.sv_gates + tn * 4 * a.Be + (lo * 4u * Be + cc);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* gr = g + (unsigned)r * 4u * Be;
+                        gr[0] = rr[r]; gr[Be] = zz[r]; gr[2u * Be] = nn[r]; gr[3u * Be] = NH[r];
+                    }
+                }
+                return;
+            }
+            const int col = nb * 16 + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int grow = row0 + 4 * (lane >> 4) + r;
-                const int off = acc_frag_off(nb, lane, r);
+                const int grow = row0 + 4 * q + r;
+                const int off = off0 + 4 * r;
                 const float rr = sigmoidf(R[r]), zz = sigmoidf(Z[r]);
                 const float nn = tanh_act(NI[r] + rr * NH[r]);
                 const float hn = (1.f - zz) * nn + zz * h_cur[off];
@@ -207,6 +246,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         BD_STAMP(9);
         lds_barrier();
         BD_STAMP(10);
+        BD_KARGS_FRESH(ap);
         // ---- prior ----
         {
             const Seg segs[1] = {{h_nxt, a.w_p1, d.Kb_h}};
@@ -215,6 +255,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         BD_STAMP(11);
         lds_barrier();
         BD_STAMP(12);
+        BD_KARGS_FRESH(ap);
         {
             const Seg2 segs[1] = {{bufA, a.w_p2m, a.w_p2s, d.Kb_hd}};
             tile_dual_head_elem<1>(
@@ -240,11 +281,14 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         BD_STAMP(14);
         float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
     }
+#undef a
 }
 
 // ---- backward --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_args a) {
+__global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_args a_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    BD_KARGS(bd_imagine_bwd_args, ap);
+#define a (*ap)
     const ImgDims d(a.Be, a.S, a.A, a.Hd);
     const int row0 = blockIdx.x * 16;
     const int F = a.Be + a.S, A = a.A;
@@ -270,7 +314,6 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
     for (int i = threadIdx.x; i < 16 * a.S; i += blockDim.x) ds_plain[i] = 0.f;
     lds_barrier();
 
-    const GruWT gw{a.wt_ir, a.wt_iz, a.wt_in, a.wt_hr, a.wt_hz, a.wt_hn};
     const size_t act_stride = (size_t)a.Hm * a.N * a.Hd;
 
     for (int t = a.Hm - 1; t >= 0; --t) {
@@ -283,6 +326,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
         auto dpre_pre = [&](const float* saved, size_t tn_, int width) {
             return DprePre{saved, tn_, width, a.N, row0, lane};
         };
+        BD_KARGS_FRESH(ap);
         // ---- 1: prior sample -> (mean, raw) ----
         for (int i = tid; i < 16 * d.Kb_s * 16; i += blockDim.x) {
             const int r = i / (d.Kb_s * 16), k = i - r * (d.Kb_s * 16);
@@ -297,12 +341,14 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
             dRaw[frag_idx(r, k)] = dr;
         }
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- 2: prior hidden ----
         {
             const Seg segs[2] = {{dM, a.wt_p2m, d.Kb_s}, {dRaw, a.wt_p2s, d.Kb_s}};
             tile_linear_pre<1, 2>(segs, nullptr, a.Hd, dpre_pre(a.sv_p, tn, a.Hd), dpre_epi(dP, nullptr, tn, a.Hd));
         }
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- 3: total d belief_{t+1}; GRU gates ----
         {
             const Seg segs3[1] = {{dP, a.wt_p1, d.Kb_hd}};
@@ -350,7 +396,9 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
                 });
         }
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- 4: through W_ih / W_hh ----
+        const GruWT gw{a.wt_ir, a.wt_iz, a.wt_in, a.wt_hr, a.wt_hz, a.wt_hn};
         gru_tile_bwd(
             dR, dZ, dNI, dNH, d.Kb_h, a.Be, gw,
             [&](int nb) {
@@ -378,6 +426,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
                 }
             });
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- 5: embed layer -> d state_t (carry) and d action_t -> actor output gradients ----
         tile_linear<1>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
@@ -433,6 +482,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
                 scratch);
         }
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- 6: actor MLP backward (input detached: no gradient below layer 0) ----
         {
             const Seg segs[2] = {{dAm, a.wt_a4m, d.Kb_a}, {dAr, a.wt_a4s, d.Kb_a}};
@@ -452,6 +502,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
             }
         }
     }
+#undef a
 }
 
 }  // namespace bd

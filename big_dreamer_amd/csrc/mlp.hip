@@ -164,10 +164,13 @@ __device__ unsigned long long g_tallstamps[64];
 // ---- tall form: 16*RT rows per workgroup, ONE in-place LDS image, balanced pairs (bd_device.h: tall_sweep) ----------
 // For chains over tens of thousands of rows (the reward / value heads over every imagined transition).  Per layer:
 // sweep (accumulators stay in registers) -> barrier -> epilogue overwrites the image -> barrier.
-// Epilogue addressing is 32-bit (element offsets below 2^31, host-checked) off uniform base pointers, and a pair whose
-// 16 rows x 16 columns are all inside the matrix takes a branch-free path: with the general per-element form (64-bit
-// index products, a row and a column predicate and two optional outputs per value) the epilogue of a 200-wide layer cost
-// 10k cycles per wave against 20k for its sweep (s_memtime stamps, tools/tall_stamps.py).
+// The sweeps run in the transposed-accumulator form (bd_device.h, linear_sweep<TR>): a lane holds four consecutive
+// columns of one row, so a pair's epilogue is 4 x ELU, one ds_write_b128 into the (in-place) fragment image and one
+// 16-byte global store, under one row/column predicate per lane.  With the row-per-register accumulator layout the same
+// epilogue was 4 conflicting ds_write_b32 + 4 dword stores + per-value predicates: 10k cycles per 200-wide layer and wave
+// against 20k for its sweep (s_memtime stamps, tools/tall_stamps.py) -- and on gfx950 a wave's VALU / memory instructions
+// do NOT overlap the fp32 MFMAs of the other waves of its SIMD (tools/probes/issue_probe.hip), so every epilogue cycle is
+// a matrix-pipe cycle lost.  Element offsets are 32-bit (host-checked), widths are multiples of 4 floats.
 template <int RT>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void mlp_fwd_tall_kernel(bd_mlp_fwd_args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -181,7 +184,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
     TALL_STAMP(1);
     lds_barrier();
     TALL_STAMP(2);
-    const bool rows_full = row0 + 16 * RT <= a.M;      // workgroup-uniform
     for (int l = 0; l < a.n_layers; ++l) {
         const bd_layer L = a.layer[l];
         const bool last = (l == a.n_layers - 1);
@@ -192,37 +194,26 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
         TALL_STAMP(3 + 4 * l);
         if (!last) lds_barrier();            // every wave has read the layer's input
         TALL_STAMP(4 + 4 * l);
-        const int lane = bd_tid() & 63, c = lane & 15, q = lane >> 4;
-        const int lds_lane = ((c >> 2) * 16 + 4 * q) * 4 + (c & 3);        // float index in a fragment block, r = 0
-        const unsigned g_lane = (unsigned)(row0 + 4 * q) * (unsigned)L.N + (unsigned)c;
+        const int lane = bd_tid() & 63, m = lane & 15, g = lane >> 4;
         const unsigned N = (unsigned)L.N;
+        const unsigned g_lane = (unsigned)(row0 + m) * N + 4u * g;           // element offset at rt = 0, nb = 0
         tall_foreach<RT>(L.N, t, [&](int rt, int nb, floatx4 acc) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[r];
+            floatx4 v = acc;
             if (L.act) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = elu(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = elu(acc[r]);
             }
-            if (!last) {
-                float* p = img + (rt * Nb + nb) * kFragFloats + lds_lane;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p[4 * r] = v[r];
-            }
-            if (rows_full && nb * 16 + 16 <= L.N && !last) {      // uniform: the whole pair is inside the matrix
-                if (L.save) {
-                    float* __restrict__ s = L.save + (g_lane + (unsigned)(rt * 16) * N + (unsigned)(nb * 16));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s[r * N] = v[r];
-                }
+            if (!last) {      // (columns >= N of the last block are ELU(0 + 0) = 0: bias and packed weights are zero there)
+                *reinterpret_cast<floatx4*>(img + ((rt * Nb + nb) * 64 + lane) * 4) = v;
+                if (L.save && row0 + rt * 16 + m < a.M && nb * 16 + 4 * g < L.N)
+                    *reinterpret_cast<floatx4*>(L.save + (g_lane + (unsigned)(rt * 16) * N + (unsigned)(nb * 16))) = v;
             } else {
-                const int col = nb * 16 + c;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int grow = row0 + rt * 16 + 4 * q + r;
+                    const int grow = row0 + rt * 16 + m, col = nb * 16 + 4 * g + r;
                     if (grow < a.M && col < L.N) {
                         if (L.save) L.save[(unsigned)grow * N + (unsigned)col] = v[r];
-                        if (last) a.out[(unsigned)grow * (unsigned)a.ldo + (unsigned)col] = v[r];
+                        a.out[(unsigned)grow * (unsigned)a.ldo + (unsigned)col] = v[r];
                     }
                 }
             }
@@ -254,7 +245,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
         }
     }
     lds_barrier();
-    const bool rows_full = row0 + 16 * RT <= a.M;
     for (int l = a.n_layers - 1; l >= 1; --l) {
         const bd_layer_bwd L = a.layer[l];       // contraction over this layer's outputs (N) -> its inputs (K)
         const bd_layer_bwd P = a.layer[l - 1];   // whose outputs those inputs are
@@ -262,58 +252,33 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
         const Seg seg[1] = {{img, L.wt, Kb}};
         TallAcc<RT> t;
         tall_sweep<RT, 1>(seg, nullptr, L.K, t);
-        const int lane = bd_tid() & 63, c = lane & 15, q = lane >> 4;
-        const int lds_lane = ((c >> 2) * 16 + 4 * q) * 4 + (c & 3);
+        const int lane = bd_tid() & 63, m = lane & 15, g = lane >> 4;
         const unsigned N = (unsigned)P.N;
-        const unsigned g_lane = (unsigned)(row0 + 4 * q) * N + (unsigned)c;
-        // saved activations of the previous layer: requested before the barrier, consumed after it (out-of-range lanes
-        // read a clamped, valid address; their products are discarded below)
+        const unsigned g_lane = (unsigned)(row0 + m) * N + 4u * g;
+        // saved activations of the previous layer: requested before the barrier, consumed after it
         TallAcc<RT> sv;
         tall_fill<RT>(L.K, sv, [&](int rt, int nb) {
             floatx4 p = floatx4{1.f, 1.f, 1.f, 1.f};
-            if (P.act) {
-                if (rows_full && nb * 16 + 16 <= P.N) {
-                    const float* __restrict__ s = P.saved + (g_lane + (unsigned)(rt * 16) * N + (unsigned)(nb * 16));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) p[r] = s[r * N];
-                } else {
-                    const unsigned col = (unsigned)min(nb * 16 + c, P.N - 1);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        p[r] = P.saved[(unsigned)min(row0 + rt * 16 + 4 * q + r, a.M - 1) * N + col];
-                }
-            }
+            if (P.act && row0 + rt * 16 + m < a.M && nb * 16 + 4 * g < P.N)
+                p = *reinterpret_cast<const floatx4*>(P.saved + (g_lane + (unsigned)(rt * 16) * N + (unsigned)(nb * 16)));
             return p;
         });
         lds_barrier();
         tall_foreach2<RT>(L.K, t, sv, [&](int rt, int nb, floatx4 acc, floatx4 p) {
-            float v[4];
+            const bool in = row0 + rt * 16 + m < a.M && nb * 16 + 4 * g < P.N;
+            floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (in) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = P.act ? acc[r] * elu_grad_from_out(p[r]) : acc[r];
-            float* w = img + (rt * Nb + nb) * kFragFloats + lds_lane;
-            if (rows_full && nb * 16 + 16 <= P.N) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) w[4 * r] = v[r];
-                if (P.dpre) {
-                    float* __restrict__ s = P.dpre + (g_lane + (unsigned)(rt * 16) * N + (unsigned)(nb * 16));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s[r * N] = v[r];
-                }
-            } else {
-                const int col = nb * 16 + c;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int grow = row0 + rt * 16 + 4 * q + r;
-                    const bool in = grow < a.M && col < P.N;
-                    w[4 * r] = in ? v[r] : 0.f;
-                    if (in && P.dpre) P.dpre[(unsigned)grow * N + (unsigned)col] = v[r];
-                }
+                for (int r = 0; r < 4; ++r) v[r] = P.act ? acc[r] * elu_grad_from_out(p[r]) : acc[r];
+                if (P.dpre) *reinterpret_cast<floatx4*>(P.dpre + (g_lane + (unsigned)(rt * 16) * N + (unsigned)(nb * 16))) = v;
             }
+            *reinterpret_cast<floatx4*>(img + ((rt * Nb + nb) * 64 + lane) * 4) = v;
         });
         lds_barrier();
     }
     if (a.din0 != nullptr || a.din1 != nullptr) {
         const bd_layer_bwd L = a.layer[0];
+        const bool rows_full = row0 + 16 * RT <= a.M;
         tile_linear<RT>(img, cdiv(L.N, 16), L.wt, nullptr, L.K, [&](int rt, int nb, floatx4 acc) {
             const int ln = bd_tid() & 63;
             const int col = nb * 16 + (ln & 15);
@@ -420,9 +385,12 @@ int bd_mlp_forward(const bd_mlp_fwd_args* a, void* stream) {
     if (tall_enabled() && a->gD == 0 && cdiv(a->M, 16) >= (tall_mode == 2 ? 1 : kTallMinTiles)) {
         bool ok = true;
         size_t widest = (size_t)a->ldo;                            // 32-bit element offsets inside the kernel
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         for (int l = 0; l < a->n_layers; ++l) {
-            ok = ok && tall_shape_ok(a->layer[l].N, kTallRT);
-            widest = (size_t)a->layer[l].N > widest ? (size_t)a->layer[l].N : widest;
+            const bd_layer& L = a->layer[l];
+            ok = ok && tall_shape_ok(L.N, kTallRT);
+            if (l + 1 < a->n_layers) ok = ok && (L.N & 3) == 0 && al16(L.save);
+            widest = (size_t)L.N > widest ? (size_t)L.N : widest;
         }
         ok = ok && (size_t)a->M * widest < ((size_t)1 << 31);
         if (ok) return launch_tall(mlp_fwd_tall_kernel<kTallRT>, "bd_mlp_forward(tall)", a->M, KbA > KbB ? KbA : KbB,
@@ -461,8 +429,10 @@ int bd_mlp_backward(const bd_mlp_bwd_args* a, void* stream) {
     if (tall_enabled() && cdiv(a->M, 16) >= (tall_mode == 2 ? 1 : kTallMinTiles)) {
         bool ok = true;
         size_t widest = (size_t)(a->ld0 > a->ld1 ? a->ld0 : a->ld1);
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         for (int l = a->n_layers - 1; l >= 1; --l) {
-            ok = ok && tall_shape_ok(a->layer[l].K, kTallRT);
+            const bd_layer_bwd& P = a->layer[l - 1];
+            ok = ok && tall_shape_ok(a->layer[l].K, kTallRT) && (P.N & 3) == 0 && al16(P.saved) && al16(P.dpre);
             widest = (size_t)a->layer[l].K > widest ? (size_t)a->layer[l].K : widest;
         }
         ok = ok && (size_t)a->M * widest < ((size_t)1 << 31);

@@ -292,7 +292,10 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
         const float* buf = wlds + (st % kWRing) * kWStage;
         // buffer (st+2) % 3 was last read in stage st-1, which every wave has left (barrier below)
         const bool more = st + 2 < nst;
+        const int sb = (st == 10 || st == 11) ? (st - 10) * 8 : -1;
+        BD_DSTAMP(sb, 0);
         if (more) issue(wlds + ((st + 2) % kWRing) * kWStage, m_begin + (st + 2) * kWRows);
+        BD_DSTAMP(sb, 1);
         const float* Pb = buf + lrow * kWLd + my_nb0 * 16 + lcol;
         const float* Ab = buf + kWRows * kWLd + lrow * kWLd + my_kb0 * 16 + lcol;
 #pragma unroll
@@ -307,10 +310,13 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
 #pragma unroll
                 for (int j = 0; j < WK; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
         }
+        BD_DSTAMP(sb, 2);
         // stage st+1 must have landed; a full stage st+2 (no tail rows: st + 3 < nst) may stay in flight
         if (more && st + 3 < nst) wait_keep_newest();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BD_DSTAMP(sb, 3);
         lds_barrier();                 // lgkmcnt(0) (tail-row clears) + s_barrier, without draining the DMA
+        BD_DSTAMP(sb, 4);
     }
     // lane holds D[n = 4*(lane>>4) + r][k = lane&15] of each 16x16 block
     float* slab = ws + d.ws_off + (size_t)z * d.N * Kext;
@@ -327,6 +333,111 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
                         if (nn < d.N && k < Kext) slab[(size_t)nn * Kext + k] = acc[i][j][r];
                     }
                 }
+            }
+        }
+    }
+}
+
+// Dense form of the wide body for the layers of the 200-wide chains: plain row-major operands whose rows and columns
+// are 16-byte aligned (no gathered window), a tile 13 blocks tall.  Two things differ from the general body: (i) every
+// WAVE runs the instantiation that fits its own share exactly (7|6 x 4|3|2|1 blocks) instead of the workgroup's
+// largest -- on a 13 x 13 tile the padded 7 x 4 body issues 224 block-MFMAs per slice for 169 useful ones -- and the
+// wave -> share table pairs the shares so that the fullest SIMD carries 46 blocks (28 + 18), not 49; (ii) the DMA of a
+// stage is four instructions per wave off per-lane base pointers set up once (the general body re-derives alignment,
+// gather geometry and source selection per stage: 1.1-1.5k cycles per stage, s_memtime stamps).
+template <int WN, int WK>
+__device__ __forceinline__ void wgrad_dense_body(const bd_wgrad_desc& d, float* __restrict__ ws, float* wlds, int hb, int Kext,
+                                                 int z, int n0, int k0, int nb_cnt, int kb_cnt, int my_nb0, int my_kb0) {
+    const int m_begin = z * d.rows_per;
+    const int m_end = min(d.M, m_begin + d.rows_per);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    floatx4 acc[WN][WK];
+#pragma unroll
+    for (int i = 0; i < WN; ++i)
+#pragma unroll
+        for (int j = 0; j < WK; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    const int ncol = min(nb_cnt * 16, d.N - n0), kcol = min(kb_cnt * 16, d.K - k0);
+    for (int i = threadIdx.x; i < kWRing * kWStage; i += kWThreads) wlds[i] = 0.f;
+    __syncthreads();
+    if (hb && d.K >= k0 && d.K < k0 + kb_cnt * 16 && threadIdx.x < kWRing * kWRows)
+        wlds[(threadIdx.x >> 4) * kWStage + kWRows * kWLd + (threadIdx.x & 15) * kWLd + (d.K - k0)] = 1.f;
+    const bool lp = 4 * lane < ncol, la = 4 * lane < kcol;
+    const float* __restrict__ pl = d.dpre + n0 + 4 * lane;
+    const float* __restrict__ a1l = d.act1 + k0 + 4 * lane;
+    const float* __restrict__ a2l = (d.M1 < d.M ? d.act2 : d.act1) + k0 + 4 * lane;
+    auto issue = [&](float* buf, int m0) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int m = m0 + wave * 2 + rr;                      // wave-uniform
+            float* P = buf + (wave * 2 + rr) * kWLd;
+            float* A = P + kWRows * kWLd;
+            if (m < m_end) {
+                if (lp) __builtin_amdgcn_global_load_lds((glb_ptr_t)(pl + (size_t)m * d.ldp), (lds_ptr_t)P, 16, 0, 0);
+                const float* ar = m < d.M1 ? a1l + (size_t)m * d.lda1 : a2l + (size_t)(m - d.M1) * d.lda2;
+                if (la) __builtin_amdgcn_global_load_lds((glb_ptr_t)ar, (lds_ptr_t)A, 16, 0, 0);
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = lane + 64 * cc;
+                    if (c < kWLd) {
+                        P[c] = 0.f;
+                        A[c] = 0.f;
+                    }
+                }
+            }
+        }
+    };
+    const int nst = cdiv(m_end - m_begin, kWRows);
+    __syncthreads();
+    issue(wlds, m_begin);
+    if (nst > 1) issue(wlds + kWStage, m_begin + kWRows);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    const int lrow = lane >> 4, lcol = lane & 15;
+    for (int st = 0; st < nst; ++st) {
+        const float* buf = wlds + (st % kWRing) * kWStage;
+        const bool more = st + 2 < nst;
+        const int sb = (st == 10 || st == 11) ? (st - 10) * 8 : -1;
+        BD_DSTAMP(sb, 0);
+        BD_PRIO_HI();
+        if (more) issue(wlds + ((st + 2) % kWRing) * kWStage, m_begin + (st + 2) * kWRows);
+        BD_PRIO_LO();
+        BD_DSTAMP(sb, 1);
+        const float* Pb = buf + lrow * kWLd + my_nb0 * 16 + lcol;
+        const float* Ab = buf + kWRows * kWLd + lrow * kWLd + my_kb0 * 16 + lcol;
+#pragma unroll
+        for (int sl = 0; sl < kWRows / 4; ++sl) {
+            float a[WN], b[WK];
+#pragma unroll
+            for (int i = 0; i < WN; ++i) a[i] = Pb[sl * 4 * kWLd + i * 16];
+#pragma unroll
+            for (int j = 0; j < WK; ++j) b[j] = Ab[sl * 4 * kWLd + j * 16];
+#pragma unroll
+            for (int i = 0; i < WN; ++i)
+#pragma unroll
+                for (int j = 0; j < WK; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+        }
+        BD_DSTAMP(sb, 2);
+        // stage st+1 must have landed; a full stage st+2 (4 DMA instructions of this wave) may stay in flight
+        if (more && st + 3 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BD_DSTAMP(sb, 3);
+        lds_barrier();
+        BD_DSTAMP(sb, 4);
+    }
+    float* slab = ws + d.ws_off + (size_t)z * d.N * Kext;
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+#pragma unroll
+        for (int j = 0; j < WK; ++j) {
+            const int k = k0 + (my_kb0 + j) * 16 + lcol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = n0 + (my_nb0 + i) * 16 + 4 * lrow + r;
+                if (nn < d.N && k < Kext) slab[(size_t)nn * Kext + k] = acc[i][j][r];
             }
         }
     }
@@ -351,6 +462,36 @@ __global__ __launch_bounds__(kWThreads) void wgrad_wide_kernel(const bd_wgrad_de
     // The MFMA loop is branch-free over WN x WK blocks per wave, so the instantiation must fit the tile: a 4 x 12-block
     // tile (N = 64: conv layers) on the 7 x 4 body would issue 28 MFMAs per slice for 6 useful ones.
     const int hn = (nb_cnt + 1) >> 1, hk = (kb_cnt + 3) >> 2;      // blocks per wave row / wave column
+    {   // dense 13-block-tall tiles: exact per-wave instantiations (wgrad_dense_body)
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        const int ncol = min(nb_cnt * 16, d.N - n0), kcol = min(kb_cnt * 16, d.K - k0);
+        const bool dense = nb_cnt == 13 && kb_cnt >= 4 && d.g_nseg == 0 && (ncol & 3) == 0 && (d.ldp & 3) == 0 &&
+                           al16(d.dpre + n0) && (kcol & 3) == 0 && (k0 & 3) == 0 && (d.lda1 & 3) == 0 && al16(d.act1) &&
+                           (d.M1 == d.M || ((d.lda2 & 3) == 0 && al16(d.act2)));
+        if (dense) {
+            const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            // hardware waves w and w+4 share a SIMD: (n half, k quarter) pairs 28+18, 24+18, 21+21, 21+18 on a 13 x 13 tile
+            // (n half, k quarter) of wave w:  w0 (0,0)  w1 (1,0)  w2 (0,1)  w3 (0,2)  w4 (1,3)  w5 (1,2)  w6 (0,3)  w7 (1,1)
+            const int wr = (0xB2 >> wave) & 1;
+            const int c = (0x13232100 >> (4 * wave)) & 3;
+            const int kq = kb_cnt >> 2, krem = kb_cnt & 3;
+            const int my_nb0 = wr ? 7 : 0, my_nb = wr ? 6 : 7;
+            const int my_kb0 = c * kq + min(c, krem), my_kb = kq + (c < krem ? 1 : 0);
+#define BD_WD(WN, WK) wgrad_dense_body<WN, WK>(d, ws, wlds, hb, Kext, z, n0, k0, nb_cnt, kb_cnt, my_nb0, my_kb0)
+#define BD_WD_ROW(WN)                 \
+    do {                              \
+        if (my_kb == 4) BD_WD(WN, 4); \
+        else if (my_kb == 3) BD_WD(WN, 3); \
+        else if (my_kb == 2) BD_WD(WN, 2); \
+        else BD_WD(WN, 1);            \
+    } while (0)
+            if (my_nb == 7) BD_WD_ROW(7);
+            else BD_WD_ROW(6);
+#undef BD_WD_ROW
+#undef BD_WD
+            return;
+        }
+    }
 #define BD_WG_BODY(WN, WK) wgrad_wide_body<WN, WK>(d, ws, wlds, hb, Kext, z, n0, k0, nb_cnt, kb_cnt)
 #define BD_WG_ROW(WN)                      \
     do {                                   \
@@ -383,6 +524,12 @@ __global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(const bd_wgra
     if (k < d.K) d.dW[(size_t)nn * d.ldw + k] = s;
     else d.db[nn] = s;
 }
+
+#ifdef BD_STAMPS
+extern "C" int bd_debug_wstamps(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dstamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // BD_WGRAD_WIDE=0 selects the 64x64-tile grouped kernel; BD_WGRAD_ROWS = rows per workgroup of the wide form
 static bool wgrad_wide() {

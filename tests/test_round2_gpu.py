@@ -231,6 +231,39 @@ def test_weight_stationary_chain_matches_the_per_tile_chain():
         assert float((x - y).abs().max()) <= 2e-6 * max(1.0, scale), (i, float((x - y).abs().max()), scale)
 
 
+def test_tall_chain_matches_the_per_tile_chain():
+    """csrc/mlp.hip, tall form of bd_mlp_forward / bd_mlp_backward (48-row workgroups, balanced (row tile, column block)
+    pairs, transposed accumulators, in-place LDS image; the default for M >= 8192 rows): outputs, saved activations,
+    d/d features (plain and accumulating) and pre-activation gradients of the head chain against the 16-row kernels, on a
+    row count that leaves a ragged last workgroup.  Same fp32 MFMA products, same summation order within a dot product."""
+    from big_dreamer_amd import _cabi as cabi
+    from big_dreamer_amd.engine import DreamerEngine
+    d = synth.CONFIG2
+    eng = DreamerEngine(d, None, "cuda", params=synth.make_params(d, 4))
+    Mi, F = d.Hm * d.N + 7, d.Be + d.S
+    g = torch.Generator(device="cuda").manual_seed(2)
+    ifeat = torch.randn(Mi, F, device="cuda", generator=g)
+    d_r = torch.randn(Mi, device="cuda", generator=g)
+    seed_din = torch.randn(Mi, F, device="cuda", generator=g)
+    keep = {}
+    try:
+        for mode in (0, 1):
+            cabi.lib.bd_mlp_set_tall(mode)
+            r_out, r_acts, r_layers = eng.dense_forward("reward_model", "rew", f"tt{mode}", ifeat, F, Mi, 1)
+            difeat = torch.zeros(Mi, F, device="cuda")
+            dacc = seed_din.clone()
+            dpre = [torch.zeros(Mi, d.Hd, device="cuda") for _ in range(4)]
+            eng.mlp_backward(Mi, d_r, 1, r_layers, r_acts + [None], dpre + [None], din0=difeat, ld0=F, w0=F)
+            eng.mlp_backward(Mi, d_r, 1, r_layers, r_acts + [None], None, din0=dacc, ld0=F, w0=F, accumulate=True)
+            torch.cuda.synchronize()
+            keep[mode] = [r_out.clone()] + [x.clone() for x in r_acts] + [difeat, dacc] + dpre
+    finally:
+        cabi.lib.bd_mlp_set_tall(-1)
+    for i, (x, y) in enumerate(zip(keep[0], keep[1])):
+        scale = float(x.abs().max())
+        assert float((x - y).abs().max()) <= 2e-6 * max(1.0, scale), (i, float((x - y).abs().max()), scale)
+
+
 def test_exact_math_build():
     """The -DBD_EXACT_MATH build (libm-grade ELU / sigmoid / tanh / softplus in the epilogues; `make exact`, built by
     __graft_entry__.build()) loaded through BD_LIB in a fresh process: two train steps of the `small` case against the

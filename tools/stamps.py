@@ -46,6 +46,10 @@ if fn3 is not None:
         print("    inside the contraction: to first stamp", si[0] - st[1], "| loads+MFMAs", si[1] - si[0], "| partials->LDS", si[2] - si[1],
               "| barrier", si[3] - si[2], "| reduce", si[4] - si[3], "| plain stores", si[5] - si[4], "| return", st[2] - si[5])
 
+    sd = np.array(out3[32:38], dtype=np.int64)
+    print("actor layer 2 (200x200), wave 0 (2 blocks): bias+pre", sd[1] - sd[0], "| K loop", sd[2] - sd[1], "| epilogue", sd[3] - sd[2],
+          "| return", sd[4] - sd[3], "| barrier", sd[5] - sd[4])
+
 # ---- cluster observe scan (forward), member 0 of tile 0, step 5 ----
 fn2 = getattr(_cabi.lib, "bd_debug_cstamps", None)
 if fn2 is not None:
