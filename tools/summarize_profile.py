@@ -79,7 +79,8 @@ if os.path.exists(os.path.join(src, "bench.json")):
     stats_csv = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
     shutil.copy(stats_csv, os.path.join(dst, f"{tag}_kernel_stats.csv"))
     names = {"imagine_fwd": "imagine_fwd_kernel", "imagine_bwd": "imagine_bwd_kernel", "observe_fwd": "observe_cfwd_kernel",
-             "observe_bwd": "observe_cbwd_kernel", "mlp_fwd (all launches, mean)": "mlp_fwd_kernel",
+             "observe_bwd": "observe_cbwd_kernel", "mlp_fwd_tall (34 300-row chains, mean)": "mlp_fwd_tall_kernel",
+             "mlp_bwd_tall (34 300-row chains, mean)": "mlp_bwd_tall_kernel", "mlp_fwd (all launches, mean)": "mlp_fwd_kernel",
              "mlp_bwd (all launches, mean)": "mlp_bwd_kernel", "wgrad_wide (all launches, mean)": "wgrad_wide_kernel",
              "dense_ws (all launches, mean)": "dense_ws"}
     traffic = traffic_of(pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq"), names)
