@@ -96,9 +96,11 @@ __device__ __forceinline__ void gather_payload(const float* __restrict__ src, fl
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_args a, float* __restrict__ ws, int C,
+__global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_args a_, float* __restrict__ ws, int C,
                                                                 int tiles, unsigned spin_limit) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    BD_KARGS(bd_observe_fwd_args, ap);      // first kernel argument: offset 0 of the kernarg segment
+#define a (*ap)
     const ObsDimsC d(a.Be, a.S, a.A, a.Hd);
     const int tile = blockIdx.x / C, c = blockIdx.x - tile * C;
     const int row0 = tile * 16;
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
         const int lane = tid & 63, wave = bd_wave(tid);
         const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(xf) + lane;
         BD_CSTAMP(0);
+        BD_KARGS_FRESH(ap);
         // ---- A: masked state / action fragments (every member) ----
         for (int i = tid; i < 16 * d.Kb_s * 16; i += blockDim.x) {
             const int r = i / (d.Kb_s * 16), k = i - r * (d.Kb_s * 16);
@@ -153,6 +156,7 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
         }
         lds_barrier();
         BD_CSTAMP(1);
+        BD_KARGS_FRESH(ap);
         // ---- B: embed (every member, full width) ----
         {
             const Seg segs[2] = {{sf, a.w_embed_s, d.Kb_s}, {af, a.w_embed_a, d.Kb_a}};
@@ -169,6 +173,7 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
         }
         lds_barrier();
         BD_CSTAMP(2);
+        BD_KARGS_FRESH(ap);
         // ---- C: GRU, this member's column blocks, K split over the waves ----
         const int my_nb = c + wave * C;                      // wave bi reduces block bi
         const bool reducer = wave < kLocalBlocks && my_nb < Nb;
@@ -263,6 +268,7 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
         gather_payload(xbuf + (size_t)(t & 1) * nh, h_nxt, nh);
         lds_barrier();
         BD_CSTAMP(8);
+        BD_KARGS_FRESH(ap);
         // ---- D: posterior hidden (every member, full width) ----
         {
             const Seg segs[1] = {{h_nxt, a.w_q1h, d.Kb_h}};
@@ -292,6 +298,7 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
         }
         lds_barrier();
         BD_CSTAMP(9);
+        BD_KARGS_FRESH(ap);
         // ---- E: posterior mean / std / sample (every member; split-K over waves) ----
         {
             const Seg2 segs[1] = {{qf, a.w_q2m, a.w_q2s, d.Kb_hd}};
@@ -319,12 +326,15 @@ __global__ __launch_bounds__(kThreads) void observe_cfwd_kernel(bd_observe_fwd_a
         BD_CSTAMP(10);
         float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
     }
+#undef a
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_args a, float* __restrict__ ws, int C,
+__global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_args a_, float* __restrict__ ws, int C,
                                                                 int tiles, unsigned spin_limit) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    BD_KARGS(bd_observe_bwd_args, ap);      // first kernel argument: offset 0 of the kernarg segment
+#define a (*ap)
     const ObsDimsC d(a.Be, a.S, a.A, a.Hd);
     const int tile = blockIdx.x / C, c = blockIdx.x - tile * C;
     const int row0 = tile * 16;
@@ -360,6 +370,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
         const int tid = bd_tid();                   // opaque: nothing thread-dependent leaves this step (bd_tid)
         const int lane = tid & 63, wave = bd_wave(tid);
         ++epoch;
+        BD_KARGS_FRESH(ap);
         // ---- 1: through the sample / softplus into (mean, raw) (every member) ----
         for (int i = tid; i < 16 * d.Kb_s * 16; i += blockDim.x) {
             const int r = i / (d.Kb_s * 16), k = i - r * (d.Kb_s * 16);
@@ -380,6 +391,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
             dRaw[frag_idx(r, k)] = dr;
         }
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- 2: d q (every member) ----
         {
             const Seg segs[2] = {{dM, a.wt_q2m, d.Kb_s}, {dRaw, a.wt_q2s, d.Kb_s}};
@@ -410,6 +422,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
                 });
         }
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- 3: total d belief_{t+1}, GRU gate gradients (every member, full width) ----
         {
             const Seg segs3[1] = {{dQ, a.wt_q1h, d.Kb_hd}};
@@ -463,6 +476,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
                 });
         }
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- 4: through W_ih / W_hh: this member's column blocks, K split over the waves ----
         const int my_nb = c + wave * C;
         const bool reducer = wave < kLocalBlocks && my_nb < Nb;
@@ -547,6 +561,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
         wait_all(flags, C, epoch, err, spin_limit, kErrBwd);
         gather_payload(xbuf + (size_t)(epoch & 1) * (2 * nh), dhc, 2 * nh);
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- 5: d posterior_state_t through the embed layer and the nonterminal mask (every member) ----
         tile_linear<1>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
@@ -562,6 +577,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
         }, scratch);
         lds_barrier();
     }
+#undef a
 }
 
 // Cluster size: one GRU column block per member while all tiles*Nb workgroups stay co-resident (measured best:

@@ -115,8 +115,10 @@ __device__ __forceinline__ void write_onehot(const CatGeo& g, const int* __restr
 // =====================================================================================================================
 // observe, forward
 // =====================================================================================================================
-__global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_cat_fwd_args a) {
+__global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_cat_fwd_args a_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    BD_KARGS(bd_observe_cat_fwd_args, ap);
+#define a (*ap)
     const CatGeo g(a.D, a.C);
     const int Kb_h = cdiv(a.Be, 16), Kb_a = cdiv(a.A, 16), Kb_hd = cdiv(a.Hd, 16);
     const int lane = threadIdx.x & 63;
@@ -145,6 +147,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
     for (int t = 0; t < a.T; ++t) {
         const size_t tb = (size_t)t * a.B;
         CAT_STAMP(0);
+        BD_KARGS_FRESH(ap);
         // ---- A: mask, action fragments ----
         if (threadIdx.x < 16)
             mrow[threadIdx.x] = (a.nonterm && row0 + (int)threadIdx.x < a.B) ? a.nonterm[tb + row0 + threadIdx.x] : 1.f;
@@ -155,12 +158,14 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
         }
         lds_barrier();
         CAT_STAMP(1);
+        BD_KARGS_FRESH(ap);
         // ---- A2: W_es s~ as a gather; the masked state for the embed weight gradient ----
         state_gather(g, a.w_embed_sT, a.Be, sidx_l, sw_l, mrow, xs);
         CAT_STAMP(2);
         if (a.sv_s) write_onehot(g, sidx_l, sw_l, mrow, a.sv_s + (tb + row0) * S, (size_t)S, rows_valid);
         lds_barrier();
         CAT_STAMP(3);
+        BD_KARGS_FRESH(ap);
         // ---- B: x = ELU(W_es s~ + W_ea a + b_e) ----
         {
             const Seg segs[1] = {{af, a.w_embed_a, Kb_a}};
@@ -178,6 +183,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
         }
         lds_barrier();
         CAT_STAMP(4);
+        BD_KARGS_FRESH(ap);
         // ---- C: GRU ----
         gru_tile(xf, h_cur, Kb_h, a.Be, gw, [&](int nb, floatx4 R, floatx4 Z, floatx4 NI, floatx4 NH) {
             const int col = nb * 16 + (lane & 15);
@@ -201,6 +207,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
         });
         lds_barrier();
         CAT_STAMP(5);
+        BD_KARGS_FRESH(ap);
         // ---- D: posterior hidden ----
         tile_linear<1>(h_nxt, Kb_h, a.w_q1h, a.b_q1, a.Hd, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
@@ -215,6 +222,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
         });
         lds_barrier();
         CAT_STAMP(6);
+        BD_KARGS_FRESH(ap);
         // ---- E: posterior logits, sample ----
         cat_head_forward_full(gf, qf, Kb_hd, a.w_q2, a.b_q2, a.q_post + (tb + row0) * S, a.post_logits + (tb + row0) * S,
                               rows_valid, lg, sidx_l);
@@ -230,6 +238,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
         CAT_STAMP(9);
         float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
     }
+#undef a
 }
 
 // The head's backward shared by both scans.  On entry dE holds d(embed pre-activation) of the step AFTER this one
@@ -349,8 +358,10 @@ __device__ __forceinline__ void cat_head_backward(const CatGeo& g, bool have_car
 // =====================================================================================================================
 // observe, backward
 // =====================================================================================================================
-__global__ __launch_bounds__(kThreads) void observe_cat_bwd_kernel(bd_observe_cat_bwd_args a) {
+__global__ __launch_bounds__(kThreads) void observe_cat_bwd_kernel(bd_observe_cat_bwd_args a_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    BD_KARGS(bd_observe_cat_bwd_args, ap);
+#define a (*ap)
     const CatGeo g(a.D, a.C);
     const int Kb_h = cdiv(a.Be, 16), Kb_hd = cdiv(a.Hd, 16);
     const int row0 = blockIdx.x * 16;
@@ -385,6 +396,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_bwd_kernel(bd_observe_ca
             mrow[tid] = (a.nonterm && t + 1 < a.T && row0 + tid < a.B) ? a.nonterm[tb + a.B + row0 + tid] : 1.f;
         lds_barrier();
         CAT_STAMP(17);
+        BD_KARGS_FRESH(ap);
         // ---- 1: d posterior logits_t, d posterior hidden ----
         floatx4 accQ[NACC];
         cat_head_backward<NACC>(g, t + 1 < a.T, dE, Kb_h, a.wt_embed_s, mrow, a.dfeat + (tb + row0) * F + a.Be, (size_t)F,
@@ -410,6 +422,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_bwd_kernel(bd_observe_ca
         }
         lds_barrier();
         CAT_STAMP(19);
+        BD_KARGS_FRESH(ap);
         // ---- 3: total d belief_{t+1}, GRU gate gradients ----
         tile_linear<1>(dQ, Kb_hd, a.wt_q1h, nullptr, a.Be, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
@@ -442,6 +455,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_bwd_kernel(bd_observe_ca
         });
         lds_barrier();
         CAT_STAMP(20);
+        BD_KARGS_FRESH(ap);
         // ---- 4: through W_ih / W_hh: d embed pre-activation (the carry to step t-1's head), d belief_t ----
         gru_tile_bwd(
             dR, dZ, dNI, dNH, Kb_h, a.Be, gw,
@@ -473,13 +487,16 @@ __global__ __launch_bounds__(kThreads) void observe_cat_bwd_kernel(bd_observe_ca
         lds_barrier();
         CAT_STAMP(21);
     }
+#undef a
 }
 
 // =====================================================================================================================
 // imagination, forward
 // =====================================================================================================================
-__global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_cat_fwd_args a) {
+__global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_cat_fwd_args a_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    BD_KARGS(bd_imagine_cat_fwd_args, ap);
+#define a (*ap)
     const CatGeo g(a.D, a.C);
     const int Kb_h = cdiv(a.Be, 16), Kb_a = cdiv(a.A, 16), Kb_hd = cdiv(a.Hd, 16);
     const int row0 = blockIdx.x * 16;
@@ -527,6 +544,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
         auto hidden_epi = [&](float* dst, float* save, size_t tn_, int width) {
             return HiddenEpi{dst, save, tn_, width, a.N, row0, lane};
         };
+        BD_KARGS_FRESH(ap);
         // ---- actor layer 0: W_a0h h + gather(W_a0s, s) ----
         state_gather(g, a.w_a0sT, a.Hd, sidx_l, sw_l, nullptr, xs);
         lds_barrier();
@@ -556,6 +574,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
                 float* tmp = src; src = dst; dst = tmp;
             }
         }
+        BD_KARGS_FRESH(ap);
         // ---- actor output, action sample (layer-3 activations are in bufB) ----
         {
             const Seg2 segs[1] = {{bufB, a.w_a4m, a.w_a4s, Kb_hd}};
@@ -584,6 +603,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
                 });
         }
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- entropy: n_samples draws per (row, action dim); thread = (row, sample lane) ----
         {
             const int row = tid & 15, sl = tid >> 4;
@@ -631,6 +651,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
             for (int j = 0; j < A; ++j) s += lp_rj[tid * A + j];
             a.entropy[tn + row0 + tid] = -s * inv_ns;
         }
+        BD_KARGS_FRESH(ap);
         // ---- embed ----
         {
             const Seg segs[1] = {{af, a.w_embed_a, Kb_a}};
@@ -647,6 +668,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
             });
         }
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- GRU ----
         gru_tile(xf, h_cur, Kb_h, a.Be, gw, [&](int nb, floatx4 R, floatx4 Z, floatx4 NI, floatx4 NH) {
             const int col = nb * 16 + (lane & 15);
@@ -669,6 +691,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
             }
         });
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- prior hidden, logits, sample ----
         {
             const Seg segs[1] = {{h_nxt, a.w_p1, Kb_h}};
@@ -683,13 +706,16 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
         lds_barrier();
         float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
     }
+#undef a
 }
 
 // =====================================================================================================================
 // imagination, backward
 // =====================================================================================================================
-__global__ __launch_bounds__(kThreads) void imagine_cat_bwd_kernel(bd_imagine_cat_bwd_args a) {
+__global__ __launch_bounds__(kThreads) void imagine_cat_bwd_kernel(bd_imagine_cat_bwd_args a_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    BD_KARGS(bd_imagine_cat_bwd_args, ap);
+#define a (*ap)
     const CatGeo g(a.D, a.C);
     const int Kb_h = cdiv(a.Be, 16), Kb_a = cdiv(a.A, 16), Kb_hd = cdiv(a.Hd, 16);
     const int row0 = blockIdx.x * 16;
@@ -731,6 +757,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_bwd_kernel(bd_imagine_ca
         auto dpre_pre = [&](const float* saved, size_t tn_, int width) {
             return DprePre{saved, tn_, width, a.N, row0, lane};
         };
+        BD_KARGS_FRESH(ap);
         // ---- 1: d prior logits_t (straight-through), d prior hidden ----
         floatx4 accP[NACC];
         cat_head_backward<NACC>(g, t + 1 < a.Hm, dE, Kb_h, a.wt_embed_s, nullptr, a.dfeat + (tn + row0) * F + a.Be, (size_t)F,
@@ -754,6 +781,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_bwd_kernel(bd_imagine_ca
             }
         }
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- 3: total d belief_{t+1}; GRU gates ----
         {
             const Seg segs3[1] = {{dP, a.wt_p1, Kb_hd}};
@@ -801,6 +829,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_bwd_kernel(bd_imagine_ca
                 });
         }
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- 4: through W_ih / W_hh ----
         gru_tile_bwd(
             dR, dZ, dNI, dNH, Kb_h, a.Be, gw,
@@ -829,6 +858,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_bwd_kernel(bd_imagine_ca
                 }
             });
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- 5: embed layer -> d action_t -> actor output gradients (d state_t is taken by the next iteration's head) ----
         {
             const Seg segs5[1] = {{dE, a.wt_embed_a, Kb_h}};
@@ -875,6 +905,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_bwd_kernel(bd_imagine_ca
                 scratch);
         }
         lds_barrier();
+        BD_KARGS_FRESH(ap);
         // ---- 6: actor MLP backward (input detached: no gradient below layer 0) ----
         {
             const Seg segs[2] = {{dAm, a.wt_a4m, Kb_a}, {dAr, a.wt_a4s, Kb_a}};
@@ -894,6 +925,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_bwd_kernel(bd_imagine_ca
             }
         }
     }
+#undef a
 }
 
 }  // namespace bd
