@@ -158,7 +158,6 @@ _SIGS = {
     "bd_pack_weights": (I32, [P, I32, P]),
     "bd_mlp_forward": (I32, [C.POINTER(MlpFwdArgs), P]),
     "bd_mlp_backward": (I32, [C.POINTER(MlpBwdArgs), P]),
-    "bd_chain_ws_set_mode": (I32, [I32]),
     "bd_mlp_set_tall": (I32, [I32]),
     "bd_wgrad_ws_floats": (C.c_size_t, [I32, I32, I32]),
     "bd_wgrad": (I32, [P, I32, P, I32, I32, I32, I32, P, I32, P, I32, P, C.c_size_t, P]),

@@ -7,12 +7,6 @@
 
 namespace bd {
 
-// weight-stationary form for tall chains (chain_ws.hip)
-bool chain_ws_forward_ok(const bd_mlp_fwd_args* a);
-int chain_ws_forward(const bd_mlp_fwd_args* a, hipStream_t s);
-bool chain_ws_backward_ok(const bd_mlp_bwd_args* a);
-int chain_ws_backward(const bd_mlp_bwd_args* a, hipStream_t s);
-
 // ---- forward --------------------------------------------------------------------------------------
 template <int RT>
 __global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, int KbA, int KbB) {
@@ -381,7 +375,6 @@ int bd_mlp_forward(const bd_mlp_fwd_args* a, void* stream) {
         kb = cdiv(L.K, 16) > kb ? cdiv(L.K, 16) : kb;
         k = L.N;
     }
-    if (chain_ws_forward_ok(a)) return chain_ws_forward(a, (hipStream_t)stream);
     if (tall_enabled() && a->gD == 0 && cdiv(a->M, 16) >= (tall_mode == 2 ? 1 : kTallMinTiles)) {
         bool ok = true;
         size_t widest = (size_t)a->ldo;                            // 32-bit element offsets inside the kernel
@@ -425,7 +418,6 @@ int bd_mlp_backward(const bd_mlp_bwd_args* a, void* stream) {
         kb = cdiv(L.N, 16) > kb ? cdiv(L.N, 16) : kb;
     }
     if (want_din) BD_REQUIRE(a->w0 + a->w1 == a->layer[0].K, "bd_mlp_backward: din widths != K of layer 0");
-    if (chain_ws_backward_ok(a)) return chain_ws_backward(a, (hipStream_t)stream);
     if (tall_enabled() && cdiv(a->M, 16) >= (tall_mode == 2 ? 1 : kTallMinTiles)) {
         bool ok = true;
         size_t widest = (size_t)(a->ld0 > a->ld1 ? a->ld0 : a->ld1);

@@ -95,16 +95,13 @@ typedef struct {
     int accumulate;                 /* 1: din += , 0: din =                                         */
 } bd_mlp_bwd_args;
 int bd_mlp_backward(const bd_mlp_bwd_args* a, void* stream);
-/* Tall chains (M >= 16384 rows: the heads over the imagined trajectories) also have a weight-stationary persistent form
- * (csrc/chain_ws.hip) behind the two entry points above; same arguments, same results.  mode 0: per-tile form (the
- * default), 1: weight-stationary forward, 2: weight-stationary forward and backward, -1: as the environment says
- * (BD_CHAIN_WS=1|2; unset = off: measured no faster inside the three-stream step). */
-int bd_chain_ws_set_mode(int mode);
 
 /* Tall form of the two chain entry points (csrc/mlp.hip, mlp_*_tall_kernel): for M >= 8192 rows and layer widths of at
  * most 15 column blocks, 48-row workgroups with one in-place LDS image and (row tile, column block) pairs balanced over
- * the four waves.  Same arguments, same results (summation order within a dot product is unchanged).  mode 1: on (the
- * default), 0: always the 16/32-row form, -1: as the environment says (BD_MLP_TALL=0 switches it off). */
+ * the four waves, accumulators in the transposed (row x 4 consecutive columns) form; layer widths must be multiples of
+ * 4 floats and saved / dpre buffers 16-byte aligned, otherwise the 16-row form runs.  Same arguments, same results
+ * (summation order within a dot product is unchanged).  mode 1: on (the default), 0: always the 16/32-row form,
+ * 2: on for every M (diagnostics), -1: as the environment says (BD_MLP_TALL=0 switches it off). */
 int bd_mlp_set_tall(int mode);
 
 /* dW[N x K] (+)= dpre^T[N x M] * act[M x K],  db[N] (+)= column sums of dpre (db may be NULL).

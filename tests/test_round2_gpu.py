@@ -202,35 +202,6 @@ def test_non_contiguous_operands_are_rejected():
         cabi.ptr(torch.zeros(4, 5, 6, device="cuda").permute(1, 0, 2))
 
 
-def test_weight_stationary_chain_matches_the_per_tile_chain():
-    """csrc/chain_ws.hip (optional form of bd_mlp_forward / bd_mlp_backward for tall inputs, off by default): forward
-    outputs, saved activations, d/d features and pre-activation gradients of the 34 300-row head chain against the
-    per-tile kernels (same fp32 MFMA products; only the grouping of partial sums differs)."""
-    from big_dreamer_amd import _cabi as cabi
-    from big_dreamer_amd.engine import DreamerEngine
-    d = synth.CONFIG2
-    eng = DreamerEngine(d, None, "cuda", params=synth.make_params(d, 3))
-    Mi, F = d.Hm * d.N + 5, d.Be + d.S                 # ragged last tile
-    g = torch.Generator(device="cuda").manual_seed(1)
-    ifeat = torch.randn(Mi, F, device="cuda", generator=g)
-    d_r = torch.randn(Mi, device="cuda", generator=g)
-    keep = {}
-    try:
-        for mode in (0, 2):
-            cabi.lib.bd_chain_ws_set_mode(mode)
-            r_out, r_acts, r_layers = eng.dense_forward("reward_model", "rew", f"t{mode}", ifeat, F, Mi, 1)
-            difeat = torch.zeros(Mi, F, device="cuda")
-            dpre = [torch.zeros(Mi, d.Hd, device="cuda") for _ in range(4)]
-            eng.mlp_backward(Mi, d_r, 1, r_layers, r_acts + [None], dpre + [None], din0=difeat, ld0=F, w0=F)
-            torch.cuda.synchronize()
-            keep[mode] = [r_out.clone()] + [x.clone() for x in r_acts] + [difeat] + dpre
-    finally:
-        cabi.lib.bd_chain_ws_set_mode(-1)
-    for i, (x, y) in enumerate(zip(keep[0], keep[2])):
-        scale = float(x.abs().max())
-        assert float((x - y).abs().max()) <= 2e-6 * max(1.0, scale), (i, float((x - y).abs().max()), scale)
-
-
 def test_tall_chain_matches_the_per_tile_chain():
     """csrc/mlp.hip, tall form of bd_mlp_forward / bd_mlp_backward (48-row workgroups, balanced (row tile, column block)
     pairs, transposed accumulators, in-place LDS image; the default for M >= 8192 rows): outputs, saved activations,

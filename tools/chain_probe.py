@@ -47,8 +47,8 @@ def main():
     head_fl = 2.0 * Mi * (F * 200 + 3 * 200 * 200 + 200)
     d_r = torch.randn(Mi, device="cuda")
     keep = {}
-    for mode, name in ((0, "per-tile chain (mlp.hip)"), (1, "weight-stationary (chain_ws.hip)")):
-        lib.bd_chain_ws_set_mode(mode)
+    for mode, name in ((0, "per-tile chain (16 rows)"), (1, "tall chain (48 rows)")):
+        lib.bd_mlp_set_tall(mode)
         print(f"--- {name} ---")
         t = timed(lambda: eng.dense_forward("reward_model", "rew", "ir", ifeat, F, Mi, 1))
         print(f"head chain forward (230->200x4->1, saves): {t:.1f} us = {head_fl / t / 1e6:.1f} TFLOP/s")
@@ -65,12 +65,12 @@ def main():
     layers = eng._dense_spec("reward_model", "rew", F, 1)
     out1 = torch.empty(Mi, 1, device="cuda")
     for mode in (0, 1):
-        lib.bd_chain_ws_set_mode(mode)
+        lib.bd_mlp_set_tall(mode)
         t = timed(lambda: eng.mlp_forward(Mi, ifeat, F, F, layers, None, out1, 1))
         print(f"mode {mode}: head chain forward WITHOUT saves: {t:.1f} us = {head_fl / t / 1e6:.1f} TFLOP/s")
     for i, (x, y) in enumerate(zip(keep[0], keep[1])):
-        print(f"  tensor {i}: max |ws - per-tile| = {(x - y).abs().max().item():.3e} (scale {x.abs().max().item():.3e})")
-    lib.bd_chain_ws_set_mode(-1)
+        print(f"  tensor {i}: max |tall - per-tile| = {(x - y).abs().max().item():.3e} (scale {x.abs().max().item():.3e})")
+    lib.bd_mlp_set_tall(-1)
 
     def wg():
         wc = eng._wbatch["critic"]
