@@ -292,7 +292,7 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
         const float* buf = wlds + (st % kWRing) * kWStage;
         // buffer (st+2) % 3 was last read in stage st-1, which every wave has left (barrier below)
         const bool more = st + 2 < nst;
-        const int sb = (st == 10 || st == 11) ? (st - 10) * 8 : -1;
+        [[maybe_unused]] const int sb = (st == 10 || st == 11) ? (st - 10) * 8 : -1;   // diagnostic stamps (-DBD_STAMPS)
         BD_DSTAMP(sb, 0);
         if (more) issue(wlds + ((st + 2) % kWRing) * kWStage, m_begin + (st + 2) * kWRows);
         BD_DSTAMP(sb, 1);
@@ -400,7 +400,7 @@ __device__ __forceinline__ void wgrad_dense_body(const bd_wgrad_desc& d, float* 
     for (int st = 0; st < nst; ++st) {
         const float* buf = wlds + (st % kWRing) * kWStage;
         const bool more = st + 2 < nst;
-        const int sb = (st == 10 || st == 11) ? (st - 10) * 8 : -1;
+        [[maybe_unused]] const int sb = (st == 10 || st == 11) ? (st - 10) * 8 : -1;   // diagnostic stamps (-DBD_STAMPS)
         BD_DSTAMP(sb, 0);
         BD_PRIO_HI();
         if (more) issue(wlds + ((st + 2) % kWRing) * kWStage, m_begin + (st + 2) * kWRows);
