@@ -44,6 +44,14 @@ def algorithmic(d):
     rows_img = d.Hm * d.N
     flops = {"imagine_fwd": img_fwd * rows_img, "imagine_bwd": img_bwd * rows_img,
              "observe_fwd": obs_fwd * d.N, "observe_bwd": obs_fwd * d.N}
+    # dense head chains over the imagined rows (F -> Hd x4 -> 1) and the weight-gradient GEMMs of the three passes:
+    # spans of several launches, reported in kernel_tflops only (never the dominant kernel)
+    head = 2 * (F * d.Hd + 3 * d.Hd * d.Hd + d.Hd)
+    flops.update({"img_heads_fwd": 2 * head * rows_img,                 # reward + value heads
+                  "img_heads_bwd": 2 * head * rows_img,                 # both with d/d features
+                  "critic_fwd_bwd": (2 * head - 2 * F * d.Hd) * rows_img,   # forward + backward without d/d features
+                  "wgrad_gemm_critic": head * rows_img,
+                  "wgrad_gemm_actor": 2 * (actor) * rows_img})
     # SURVEY.md section 8d algorithmic bytes: observe 4*(E+A+1+2S+Be+6S), imagine 4*(101A+2S+Be+3)+66, x3 fwd+bwd
     if d.categorical:   # per transition: read emb, action, mask, S draws; write belief, D indices (as floats), 2 x S logits
         obs_b = 4 * (d.E + d.A + 1 + d.S + d.Be + d.cat_D + 2 * d.S)
@@ -290,7 +298,8 @@ def main():
         flops, step_bytes = algorithmic(d)
         # dominant kernel = the persistent kernel that carries most of the path's algorithmic FLOPs (the imagination
         # forward: 31.9 of the 63.6 GFLOP of the four scans); every kernel's rate is listed in kernel_tflops
-        dom = max((k for k in kt if k in flops), key=lambda k: flops[k])
+        scans = ("imagine_fwd", "imagine_bwd", "observe_fwd", "observe_bwd")
+        dom = max((k for k in kt if k in flops and k in scans), key=lambda k: flops[k])
         ach = flops[dom] / (kt[dom][0] * 1e-3) / 1e12
         traffic, traffic_src = measured_traffic(dom, "cat" if args.categorical else ("pixel" if args.pixel else ""))
         out = {

@@ -313,10 +313,16 @@ struct NoPre {
 // Diagnostic build only (-DBD_STAMPS): s_memtime at points inside a tile primitive, recorded by thread 0 of workgroup 0
 // when the caller passes a slot base >= 0 (each translation unit has its own table).  Never in the shipped .so.
 #ifdef BD_STAMPS
+#ifndef BD_STAMP_BLOCK
+#define BD_STAMP_BLOCK 0          // workgroup that records (-DBD_STAMP_BLOCK=n)
+#endif
+#ifndef BD_STAMP_THREAD
+#define BD_STAMP_THREAD 0
+#endif
 static __device__ unsigned long long g_dstamps[64];
 #define BD_DSTAMP(base, k)                                                                                  \
     do {                                                                                                    \
-        if ((base) >= 0 && (base) + (k) < 64 && blockIdx.x == 0 && threadIdx.x == 0)                        \
+        if ((base) >= 0 && (base) + (k) < 64 && blockIdx.x == BD_STAMP_BLOCK && threadIdx.x == BD_STAMP_THREAD) \
             g_dstamps[(base) + (k)] = __builtin_amdgcn_s_memtime();                                          \
     } while (0)
 #else

@@ -175,5 +175,24 @@ if os.path.exists(os.path.join(src, "cat_bench.json")):
     stats_table(readme, crow, 16)
     readme.write("\nHIP-event averages inside bench.py (ms): " + json.dumps(cb["kernel_ms"]) + "\n\n")
     table(readme, ctraffic)
+# ------------------------------------------------------------------------------------------------ kernels alone on the GPU
+alone = {k: glob.glob(os.path.join(src, f"alone_{k}", "*", "*_kernel_stats.csv")) for k in ("chain", "wgrad")}
+if alone["chain"] or alone["wgrad"]:
+    readme.write("\n## Dense-chain and weight-gradient kernels ALONE on the GPU (`tools/profile_alone.sh`)\n\n"
+                 "`rocprofv3 --kernel-trace --stats` around `tools/tall_probe.py` (head chain 230 -> 200 x4 -> 1 over 34 300 rows = "
+                 "11.43 GFLOP per pass; 16-row kernels against the tall form) and `tools/wgrad_stamps.py` (the critic's five "
+                 "weight-gradient GEMMs, 11.43 GFLOP).  Inside the three-stream step the same kernels run contended (table at the top).\n\n")
+    GF = 2.0 * 34300 * (230 * 200 + 3 * 200 * 200 + 200) / 1e9
+    readme.write("| kernel | calls | avg us | TFLOP/s | of the fp32 MFMA peak (157.3) |\n|---|---|---|---|---|\n")
+    for k in ("chain", "wgrad"):
+        if not alone[k]:
+            continue
+        shutil.copy(alone[k][0], os.path.join(dst, f"{tag}_alone_{k}_kernel_stats.csv"))
+        for r in csv.DictReader(open(alone[k][0])):
+            n = r["Name"]
+            if ("mlp_" in n and k == "chain") or ("wgrad_wide" in n and k == "wgrad"):
+                us = float(r["AverageNs"]) / 1e3
+                tf = GF / us * 1e3
+                readme.write(f"| `{n[:70]}` | {r['Calls']} | {us:.1f} | {tf:.1f} | {tf / 157.3:.3f} |\n")
 readme.close()
 print(open(os.path.join(dst, f"{tag}_README.md")).read())
