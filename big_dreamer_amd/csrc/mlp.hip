@@ -191,7 +191,36 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
         const int lane = bd_tid() & 63, m = lane & 15, g = lane >> 4;
         const unsigned N = (unsigned)L.N;
         const unsigned g_lane = (unsigned)(row0 + m) * N + 4u * g;           // element offset at rt = 0, nb = 0
+        const bool gather0 = l == 0 && a.gD > 0 && !last;
+        if (gather0) {
+            // layer 0's one-hot input segment: the sum of gD rows of the plain transposed weights per output row, built in
+            // the (now free) image in the accumulators' own layout -- lane (row, column group) of block nb holds four
+            // columns -- so that the epilogue below reads its 16 bytes from the address it then overwrites
+            const int N4 = L.N >> 2;
+            for (int i = bd_tid(); i < 16 * RT * N4; i += blockDim.x) {
+                const int row = i / N4, c4 = i - row * N4;
+                const int grow = row0 + row;
+                floatx4 sum = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (grow < a.M) {
+                    const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(a.gWT) + c4;
+                    const unsigned char* __restrict__ ix = a.gidx + (size_t)grow * a.gD;
+                    int f = 0;
+                    for (; f + 8 <= a.gD; f += 8) {
+                        floatx4 tt[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) tt[j] = W4[(size_t)((f + j) * a.gC + ix[f + j]) * N4];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) sum += tt[j];
+                    }
+                    for (; f < a.gD; ++f) sum += W4[(size_t)(f * a.gC + ix[f]) * N4];
+                }
+                const int rt = row >> 4, nb = c4 >> 2;
+                *reinterpret_cast<floatx4*>(img + ((rt * Nb + nb) * 64 + (c4 & 3) * 16 + (row & 15)) * 4) = sum;
+            }
+            lds_barrier();
+        }
         tall_foreach<RT>(L.N, t, [&](int rt, int nb, floatx4 acc) {
+            if (gather0 && nb * 16 + 4 * g < L.N) acc += *reinterpret_cast<const floatx4*>(img + ((rt * Nb + nb) * 64 + lane) * 4);
             floatx4 v = acc;
             if (L.act) {
 #pragma unroll
@@ -375,8 +404,11 @@ int bd_mlp_forward(const bd_mlp_fwd_args* a, void* stream) {
         kb = cdiv(L.K, 16) > kb ? cdiv(L.K, 16) : kb;
         k = L.N;
     }
-    if (tall_enabled() && a->gD == 0 && cdiv(a->M, 16) >= (tall_mode == 2 ? 1 : kTallMinTiles)) {
-        bool ok = true;
+    if (a->gD > 0)
+        BD_REQUIRE(a->gidx && a->gWT && a->gC > 0 && a->gC <= 256 && a->layer[0].N % 4 == 0,
+                   "bd_mlp_forward: one-hot segment needs gidx, gWT, 0 < gC <= 256 and N0 %% 4 == 0");
+    if (tall_enabled() && cdiv(a->M, 16) >= (tall_mode == 2 ? 1 : kTallMinTiles)) {
+        bool ok = !(a->gD > 0 && a->n_layers == 1);                // (the one-hot segment is added in a hidden layer's epilogue)
         size_t widest = (size_t)a->ldo;                            // 32-bit element offsets inside the kernel
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         for (int l = 0; l < a->n_layers; ++l) {
@@ -389,12 +421,7 @@ int bd_mlp_forward(const bd_mlp_fwd_args* a, void* stream) {
         if (ok) return launch_tall(mlp_fwd_tall_kernel<kTallRT>, "bd_mlp_forward(tall)", a->M, KbA > KbB ? KbA : KbB,
                                    (hipStream_t)stream, *a);
     }
-    size_t xs = 0;
-    if (a->gD > 0) {
-        BD_REQUIRE(a->gidx && a->gWT && a->gC > 0 && a->gC <= 256 && a->layer[0].N % 4 == 0,
-                   "bd_mlp_forward: one-hot segment needs gidx, gWT, 0 < gC <= 256 and N0 %% 4 == 0");
-        xs = (size_t)16 * a->layer[0].N;
-    }
+    const size_t xs = a->gD > 0 ? (size_t)16 * a->layer[0].N : 0;
     const int rt = pick_rt(a->M, KbA, KbB, xs);
     if (rt == 2)
         return launch_chain(mlp_fwd_kernel<2>, "bd_mlp_forward", a->M, 2, KbA, KbB, (hipStream_t)stream, *a, 2 * xs);

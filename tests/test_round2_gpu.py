@@ -235,6 +235,33 @@ def test_tall_chain_matches_the_per_tile_chain():
         assert float((x - y).abs().max()) <= 2e-6 * max(1.0, scale), (i, float((x - y).abs().max()), scale)
 
 
+def test_tall_chain_with_one_hot_segment_matches_the_per_tile_chain():
+    """Categorical latents: the dense heads read [h; one-hot s] and bd_mlp_forward takes the state as class indices (layer
+    0 = contraction over h + a gather of D rows of the transposed weights).  The tall form builds that gather sum in its
+    LDS image between layer 0's sweep and epilogue; outputs and saved activations against the 16-row kernels."""
+    from big_dreamer_amd import _cabi as cabi
+    from big_dreamer_amd.engine import DreamerEngine
+    d = synth.CONFIG5_STATE            # 32 x 32 latents, 200-wide heads
+    eng = DreamerEngine(d, None, "cuda", params=synth.make_params(d, 5))
+    Mi, F = 9000 + 5, d.Be + d.S
+    g = torch.Generator(device="cuda").manual_seed(4)
+    sidx = torch.randint(0, d.cat_C, (Mi, d.cat_D), device="cuda", generator=g).to(torch.uint8)
+    feat = torch.zeros(Mi, F, device="cuda")
+    feat[:, :d.Be] = torch.randn(Mi, d.Be, device="cuda", generator=g)
+    keep = {}
+    try:
+        for mode in (0, 1):
+            cabi.lib.bd_mlp_set_tall(mode)
+            out, acts, _ = eng.dense_forward("reward_model", "rew", f"g{mode}", feat, F, Mi, 1, sidx=sidx)
+            torch.cuda.synchronize()
+            keep[mode] = [out.clone()] + [x.clone() for x in acts]
+    finally:
+        cabi.lib.bd_mlp_set_tall(-1)
+    for i, (x, y) in enumerate(zip(keep[0], keep[1])):
+        scale = float(x.abs().max())
+        assert scale > 0 and float((x - y).abs().max()) <= 2e-6 * max(1.0, scale), (i, float((x - y).abs().max()), scale)
+
+
 def test_exact_math_build():
     """The -DBD_EXACT_MATH build (libm-grade ELU / sigmoid / tanh / softplus in the epilogues; `make exact`, built by
     __graft_entry__.build()) loaded through BD_LIB in a fresh process: two train steps of the `small` case against the
