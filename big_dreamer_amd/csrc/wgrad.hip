@@ -157,6 +157,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_grouped_kernel(const bd_wgrad_
 // double-buffered LDS image with row stride 208 (== 16 mod 32: the 2 x 16-float rows a half-wave reads fall on
 // disjoint banks); the next stage's global loads fly under this stage's MFMAs; one barrier per stage.
 constexpr int kWB = 13;               // 16-blocks per workgroup tile edge
+constexpr int kWBK = 12;              // ... along K when K needs several tiles: 3 blocks per wave column, no padded MFMAs
+__host__ __device__ __forceinline__ int wgrad_tiles_k(int KB) { return KB <= kWB ? 1 : cdiv(KB, kWBK); }
 constexpr int kWLd = 240;             // LDS row stride in floats: 14 blocks + pad, == 16 mod 32
 constexpr int kWRows = 16;            // rows per stage
 constexpr int kWStage = 2 * kWRows * kWLd;   // floats per stage: dpre rows | act rows
@@ -497,6 +499,7 @@ __global__ __launch_bounds__(kWThreads) void wgrad_wide_kernel(const bd_wgrad_de
     do {                                   \
         if (hk <= 1) BD_WG_BODY(WN, 1);    \
         else if (hk <= 2) BD_WG_BODY(WN, 2); \
+        else if (hk <= 3) BD_WG_BODY(WN, 3); \
         else BD_WG_BODY(WN, 4);            \
     } while (0)
     if (hn <= 1) BD_WG_ROW(1);
@@ -569,7 +572,7 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
         auto wgs = [&](int R) {
             long t = 0;
             for (int i = 0; i < n; ++i)
-                t += (long)cdiv(cdiv(descs[i].N, 16), kWB) * cdiv(cdiv(descs[i].K + (descs[i].db != nullptr), 16), kWB) *
+                t += (long)cdiv(cdiv(descs[i].N, 16), kWB) * wgrad_tiles_k(cdiv(descs[i].K + (descs[i].db != nullptr), 16)) *
                      cdiv(descs[i].M > 0 ? descs[i].M : 1, R);
             return t;
         };
@@ -589,7 +592,7 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
     };
     auto desc_geo = [&](const bd_wgrad_desc& d, int* tiles, int* cost) {
         const int NB = cdiv(d.N, 16), KB = cdiv(d.K + (d.db != nullptr), 16);
-        const int tn = cdiv(NB, kWB), tk = cdiv(KB, kWB);
+        const int tn = cdiv(NB, kWB), tk = wgrad_tiles_k(KB);
         *tiles = tn * tk;
         *cost = tile_cost(cdiv(NB, tn), cdiv(KB, tk));
     };
@@ -622,7 +625,7 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
         if (wgrad_wide()) {
             // tiles of <= 13 x 13 16-blocks, balanced; the row split is chosen below for the whole launch
             d.tiles_n = cdiv(cdiv(d.N, 16), kWB);
-            d.tiles_k = cdiv(cdiv(d.K + hb, 16), kWB);
+            d.tiles_k = wgrad_tiles_k(cdiv(d.K + hb, 16));
             d.rows_per = rows_wide;
             if (budget > 0.0) {
                 int t, c;
