@@ -163,12 +163,15 @@ constexpr int kWLd = 240;             // LDS row stride in floats: 14 blocks + p
 constexpr int kWRows = 16;            // rows per stage
 constexpr int kWStage = 2 * kWRows * kWLd;   // floats per stage: dpre rows | act rows
 constexpr int kWRing = 3;             // stage buffers (DMA runs two stages ahead)
+constexpr int kWRowsTall = 32;         // rows per stage of a narrow tile (<= 64 dpre columns): half the stage overhead per row
+constexpr int kWLdNarrow = 80;         // its dpre row stride: 64 + 16, == 16 mod 32
+constexpr size_t kWideLdsBytes = (size_t)kWRing * kWRowsTall * (kWLdNarrow + kWLd) * sizeof(float);   // 122 880 (>= 3 x 30 720)
 constexpr int kWThreads = 512;        // 8 waves: 2 per SIMD, so LDS latency and the stage barrier hide under the other wave
 
 // WN x WK = 16-blocks per wave (the 2 x 4 waves cover up to 2WN x 4WK blocks).  The MFMA loop is branch-free: a wave
 // whose share is smaller multiplies zero-filled LDS columns (the workgroup runs at the pace of its fullest wave
 // anyway); only the stores are guarded.
-template <int WN, int WK>
+template <int WN, int WK, int ROWS = kWRows, int PLD = kWLd>
 __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* __restrict__ ws, float* wlds, int hb, int Kext,
                                                 int z, int n0, int k0, int nb_cnt, int kb_cnt) {
     const int m_begin = z * d.rows_per;
@@ -183,6 +186,9 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
     const int kq = kb_cnt >> 2, krem = kb_cnt & 3;
     const int my_kb0 = wc * kq + min(wc, krem), my_kb = kq + (wc < krem ? 1 : 0);
 
+    constexpr int kStage = ROWS * (PLD + kWLd);     // floats per stage: ROWS dpre rows (stride PLD) | ROWS act rows (stride kWLd)
+    constexpr int kRpw = ROWS / 8;                  // rows per wave and stage
+    static_assert(kWRing * kStage * sizeof(float) <= kWideLdsBytes, "stage ring exceeds the LDS request");
     floatx4 acc[WN][WK];
 #pragma unroll
     for (int i = 0; i < WN; ++i)
@@ -197,10 +203,10 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
     const int ncol = min(nb_cnt * 16, d.N - n0), kcol = min(kb_cnt * 16, d.K - k0);   // real columns of this tile
-    for (int i = threadIdx.x; i < kWRing * kWStage; i += kWThreads) wlds[i] = 0.f;
+    for (int i = threadIdx.x; i < kWRing * kStage; i += kWThreads) wlds[i] = 0.f;
     __syncthreads();
-    if (hb && d.K >= k0 && d.K < k0 + kb_cnt * 16 && threadIdx.x < kWRing * kWRows)
-        wlds[(threadIdx.x >> 4) * kWStage + kWRows * kWLd + (threadIdx.x & 15) * kWLd + (d.K - k0)] = 1.f;
+    if (hb && d.K >= k0 && d.K < k0 + kb_cnt * 16 && threadIdx.x < kWRing * ROWS)
+        wlds[(threadIdx.x / ROWS) * kStage + ROWS * PLD + (threadIdx.x % ROWS) * kWLd + (d.K - k0)] = 1.f;
     // 16-byte LDS-DMA (one 1 KiB wave-instruction per operand row) wherever rows and columns allow it: the dword form
     // moves 256 B per instruction and ran the whole kernel at ~1.2 TB/s of operand traffic, not at its MFMA rate.
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -220,10 +226,10 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
     }
     auto issue = [&](float* buf, int m0) {
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int m = m0 + wave * 2 + rr;                      // wave-uniform
-            float* P = buf + (wave * 2 + rr) * kWLd;
-            float* A = P + kWRows * kWLd;
+        for (int rr = 0; rr < kRpw; ++rr) {
+            const int m = m0 + wave * kRpw + rr;                   // wave-uniform
+            float* P = buf + (wave * kRpw + rr) * PLD;
+            float* A = buf + ROWS * PLD + (wave * kRpw + rr) * kWLd;
             if (m < m_end) {
                 const float* prow = d.dpre + (size_t)m * d.ldp + n0;
                 if (p4) {
@@ -259,20 +265,18 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
                     const int c = lane + 64 * cc;
-                    if (c < kWLd) {
-                        P[c] = 0.f;
-                        A[c] = 0.f;
-                    }
+                    if (c < PLD) P[c] = 0.f;
+                    if (c < kWLd) A[c] = 0.f;
                 }
             }
         }
     };
-    const int nst = cdiv(m_end - m_begin, kWRows);
+    const int nst = cdiv(m_end - m_begin, ROWS);
     // Ring of three stage buffers: the DMA of stage st+2 is issued at the top of stage st, and the end of stage st only
     // waits for stage st+1 (`vmcnt(n)` with n = this wave's DMA instructions per stage leaves the newest stage in
     // flight; vmcnt retires in order).  A narrow tile (N = 32 / 64: conv layers) has ~1.5k cycles of MFMAs per
     // 16-row stage against >= 2.5k cycles of loaded DMA latency: with two buffers every stage waited for its fetch.
-    const int n_dma = 2 * ((p4 ? 1 : cdiv(ncol, 64)) + (a4 ? 1 : cdiv(kcol, 64)));       // 4, 6, ..., 16 per wave and full stage
+    const int n_dma = kRpw * ((p4 ? 1 : cdiv(ncol, 64)) + (a4 ? 1 : cdiv(kcol, 64)));    // 4, 6, ..., 16 per wave and full stage
     auto wait_keep_newest = [&]() {
         switch (n_dma) {
             case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
@@ -286,25 +290,25 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
     };
     __syncthreads();
     issue(wlds, m_begin);
-    if (nst > 1) issue(wlds + kWStage, m_begin + kWRows);
+    if (nst > 1) issue(wlds + kStage, m_begin + ROWS);
     __builtin_amdgcn_s_waitcnt(0);     // vmcnt(0) lgkmcnt(0): both have landed
     __syncthreads();
     const int lrow = lane >> 4, lcol = lane & 15;
     for (int st = 0; st < nst; ++st) {
-        const float* buf = wlds + (st % kWRing) * kWStage;
+        const float* buf = wlds + (st % kWRing) * kStage;
         // buffer (st+2) % 3 was last read in stage st-1, which every wave has left (barrier below)
         const bool more = st + 2 < nst;
         [[maybe_unused]] const int sb = (st == 10 || st == 11) ? (st - 10) * 8 : -1;   // diagnostic stamps (-DBD_STAMPS)
         BD_DSTAMP(sb, 0);
-        if (more) issue(wlds + ((st + 2) % kWRing) * kWStage, m_begin + (st + 2) * kWRows);
+        if (more) issue(wlds + ((st + 2) % kWRing) * kStage, m_begin + (st + 2) * ROWS);
         BD_DSTAMP(sb, 1);
-        const float* Pb = buf + lrow * kWLd + my_nb0 * 16 + lcol;
-        const float* Ab = buf + kWRows * kWLd + lrow * kWLd + my_kb0 * 16 + lcol;
+        const float* Pb = buf + lrow * PLD + my_nb0 * 16 + lcol;
+        const float* Ab = buf + ROWS * PLD + lrow * kWLd + my_kb0 * 16 + lcol;
 #pragma unroll
-        for (int sl = 0; sl < kWRows / 4; ++sl) {
+        for (int sl = 0; sl < ROWS / 4; ++sl) {
             float a[WN], b[WK];
 #pragma unroll
-            for (int i = 0; i < WN; ++i) a[i] = Pb[sl * 4 * kWLd + i * 16];
+            for (int i = 0; i < WN; ++i) a[i] = Pb[sl * 4 * PLD + i * 16];
 #pragma unroll
             for (int j = 0; j < WK; ++j) b[j] = Ab[sl * 4 * kWLd + j * 16];
 #pragma unroll
@@ -447,7 +451,7 @@ __device__ __forceinline__ void wgrad_dense_body(const bd_wgrad_desc& d, float* 
 
 __global__ __launch_bounds__(kWThreads) void wgrad_wide_kernel(const bd_wgrad_desc* __restrict__ descs, int n,
                                                          float* __restrict__ ws) {
-    extern __shared__ float wlds[];   // [2][ P: kWRows x kWLd | A: kWRows x kWLd ]
+    extern __shared__ float wlds[];   // ring of kWRing stages: [ P: rows x stride | A: rows x kWLd ] (kWideLdsBytes)
     int g = 0;
     while (g + 1 < n && (int)blockIdx.x >= descs[g + 1].block_begin) ++g;     // uniform scan, n is small
     const bd_wgrad_desc d = descs[g];
@@ -493,6 +497,24 @@ __global__ __launch_bounds__(kWThreads) void wgrad_wide_kernel(const bd_wgrad_de
 #undef BD_WD
             return;
         }
+    }
+    if (nb_cnt <= 4) {
+        // narrow tile (<= 64 dpre columns: conv layers with 32 / 64 output channels, the 3-channel image): a wave holds
+        // only 1-2 x 1-4 accumulators, i.e. 4-32 MFMAs per 16-row stage against ~2.5k cycles of DMA issue / wait / barrier
+        // per stage -- 32-row stages (compact dpre rows keep the ring inside the LDS) halve that overhead per row
+#define BD_WN_BODY(WN, WK) wgrad_wide_body<WN, WK, kWRowsTall, kWLdNarrow>(d, ws, wlds, hb, Kext, z, n0, k0, nb_cnt, kb_cnt)
+#define BD_WN_ROW(WN)                      \
+    do {                                   \
+        if (hk <= 1) BD_WN_BODY(WN, 1);    \
+        else if (hk <= 2) BD_WN_BODY(WN, 2); \
+        else if (hk <= 3) BD_WN_BODY(WN, 3); \
+        else BD_WN_BODY(WN, 4);            \
+    } while (0)
+        if (hn <= 1) BD_WN_ROW(1);
+        else BD_WN_ROW(2);
+#undef BD_WN_ROW
+#undef BD_WN_BODY
+        return;
     }
 #define BD_WG_BODY(WN, WK) wgrad_wide_body<WN, WK>(d, ws, wlds, hb, Kext, z, n0, k0, nb_cnt, kb_cnt)
 #define BD_WG_ROW(WN)                      \
@@ -675,7 +697,7 @@ int bd_wgrad_grouped_phase(const bd_wgrad_desc* descs_dev, int n, int total_bloc
             if (allow_big_lds(wgrad_wide_kernel)) return -1;
             lds_ok = true;
         }
-        hipLaunchKernelGGL(wgrad_wide_kernel, dim3(total_blocks), dim3(kWThreads), kWRing * kWStage * sizeof(float), (hipStream_t)stream,
+        hipLaunchKernelGGL(wgrad_wide_kernel, dim3(total_blocks), dim3(kWThreads), kWideLdsBytes, (hipStream_t)stream,
                            descs_dev, n, ws);
     } else {
         hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(total_blocks), dim3(kThreads), 0, (hipStream_t)stream, descs_dev, n, ws);
