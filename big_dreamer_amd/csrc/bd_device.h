@@ -329,212 +329,17 @@ static __device__ unsigned long long g_dstamps[64];
 #define BD_DSTAMP(base, k)
 #endif
 
-// NI column blocks nb0, nb0+kWaves, ... of this wave (all valid), RT row tiles, all segments.
-template <int NSEG, int RT, int NI, int D, class Pre, class Epi>
-__device__ __forceinline__ void linear_blocks(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, int nb0,
-                                              Pre&& pre, Epi&& epi, int sb = -1) {
-    const int lane = bd_tid() & 63;
-    BD_DSTAMP(sb, 0);
-    decltype(pre(0, 0)) pf[NI][RT];
+// Accumulators in the transposed form (linear_sweep<..., TR = true>): lane holds row lane&15, columns
+// nb*16 + 4*(lane>>4) + r.  N % 4 == 0 (host-checked by the tall chain launchers); the bias vector sits at an arbitrary
+// float offset of the flat parameter buffer, so it is read with scalar loads.
+__device__ __forceinline__ floatx4 tall_bias(const float* __restrict__ bias, int N, int nb, int lane) {
+    const int col0 = nb * 16 + 4 * (lane >> 4);
+    floatx4 b = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr && col0 < N) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) pf[i][rt] = pre(rt, nb0 + i * kWaves);
-    constexpr bool kSplit = (NI * RT == 1);   // a lone chain would pay the 40-cycle dependent-MFMA latency
-    floatx4 acc[NI][RT];
-    floatx4 acc2 = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int col = (nb0 + i * kWaves) * 16 + (lane & 15);
-        const float b = (bias != nullptr && col < N) ? bias[col] : 0.f;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[i][rt] = floatx4{b, b, b, b};
+        for (int r = 0; r < 4; ++r) b[r] = bias[col0 + r];
     }
-    BD_DSTAMP(sb, 1);
-#pragma unroll
-    for (int s = 0; s < NSEG; ++s) {
-        const int Kb = seg[s].Kb;
-        const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(seg[s].X) + lane;
-        const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(seg[s].W) + lane + (size_t)nb0 * Kb * 64;
-        const size_t wstride = (size_t)kWaves * Kb * 64;   // between this wave's column blocks
-        pipelined_k<D>(
-            Kb,
-            [&](int kb) {
-                LinFrag<RT, NI> f;
-#pragma unroll
-                for (int i = 0; i < NI; ++i) f.b[i] = W4[i * wstride + (size_t)kb * 64];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) f.a[rt] = X4[(rt * Kb + kb) * 64];
-                return f;
-            },
-            [&](const LinFrag<RT, NI>& f) {
-                if constexpr (kSplit) {
-                    acc[0][0] = mfma16(f.a[0][0], f.b[0][0], acc[0][0]);
-                    acc2 = mfma16(f.a[0][1], f.b[0][1], acc2);
-                    acc[0][0] = mfma16(f.a[0][2], f.b[0][2], acc[0][0]);
-                    acc2 = mfma16(f.a[0][3], f.b[0][3], acc2);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int i = 0; i < NI; ++i)
-#pragma unroll
-                            for (int rt = 0; rt < RT; ++rt) acc[i][rt] = mfma16(f.a[rt][j], f.b[i][j], acc[i][rt]);
-                }
-            });
-    }
-    if constexpr (kSplit) acc[0][0] += acc2;
-    BD_DSTAMP(sb, 2);
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) epi(rt, nb0 + i * kWaves, acc[i][rt], pf[i][rt]);
-    BD_DSTAMP(sb, 3);
-}
-
-
-// ---- split-K over waves for narrow outputs ----------------------------------------------------------------
-// When a layer has at most two (column block, row tile) pairs (N <= 32: the mean/std heads, the N=1 heads of the
-// reward/value chains, the d/d(state|action) of the embed layer) the column-block decomposition leaves all but
-// one or two waves idle while those walk every K block in sequence: ~one L2 round trip per block pair.  Here
-// every wave takes the K blocks kb = wave, wave+kWaves, ... of ALL pairs, partial accumulators meet in an LDS
-// scratch ([kWaves][pairs][64 lanes] float4) and the first `pairs` waves sum them in fixed order (deterministic)
-// and run the epilogue.  Costs one extra barrier, removes ~Kb/kWaves round trips from the step's critical path.
-constexpr int kSplitPairs = 2;
-constexpr int kHeadMaxN = 64;                                   // widest Gaussian head tile_dual_head_elem spreads
-constexpr int kHeadPlainFloats = 2 * 16 * kHeadMaxN;            // [2][16 rows][<= 64 columns] behind the partials
-constexpr int kSplitPartialFloats = kWaves * kSplitPairs * 2 * kFragFloats;   // dual form needs 2 outputs per pair
-constexpr int kSplitScratchFloats = kSplitPartialFloats + kHeadPlainFloats;
-
-template <int RT, int NSEG, class Pre, class Epi>
-__device__ __forceinline__ void tile_linear_splitk(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
-                                                   float* __restrict__ scratch, Pre&& pre, Epi&& epi) {
-    const int lane = bd_tid() & 63, wave = bd_wave(bd_tid());
-    const int Nb = (N + 15) >> 4;
-    const int P = Nb * RT;                      // <= kSplitPairs (checked by the caller)
-    // the reducing waves fetch their bias and epilogue operands up front
-    const int my_nb = wave / RT, my_rt = wave - my_nb * RT;
-    decltype(pre(0, 0)) pf{};
-    float my_bias = 0.f;
-    if (wave < P) {
-        pf = pre(my_rt, my_nb);
-        const int col = my_nb * 16 + (lane & 15);
-        my_bias = (bias != nullptr && col < N) ? bias[col] : 0.f;
-    }
-    floatx4 acc[kSplitPairs];
-#pragma unroll
-    for (int p = 0; p < kSplitPairs; ++p) acc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
-    // A wave's share is tiny (<= 2 K blocks x <= 2 pairs per segment for K <= 16*kWaves): issue ALL its loads
-    // before the first MFMA, so the share costs one L2 round trip instead of one per (k block, pair).
-    constexpr int KW = 2;
-#pragma unroll
-    for (int s = 0; s < NSEG; ++s) {
-        const int Kb = seg[s].Kb;
-        const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(seg[s].X) + lane;
-        const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(seg[s].W) + lane;
-        for (int kb0 = wave; kb0 < Kb; kb0 += kWaves * KW) {
-            floatx4 xa[KW][kSplitPairs], wb[KW][kSplitPairs];
-#pragma unroll
-            for (int i = 0; i < KW; ++i) {
-                const int kb = kb0 + i * kWaves;
-#pragma unroll
-                for (int p = 0; p < kSplitPairs; ++p) {
-                    if (kb < Kb && p < P) {
-                        const int nb = p / RT, rt = p % RT;
-                        xa[i][p] = X4[(rt * Kb + kb) * 64];
-                        wb[i][p] = W4[((size_t)nb * Kb + kb) * 64];
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < KW; ++i) {
-                const int kb = kb0 + i * kWaves;
-#pragma unroll
-                for (int p = 0; p < kSplitPairs; ++p) {
-                    if (kb < Kb && p < P) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[p] = mfma16(xa[i][p][j], wb[i][p][j], acc[p]);
-                    }
-                }
-            }
-        }
-    }
-    floatx4* __restrict__ S4 = reinterpret_cast<floatx4*>(scratch);
-#pragma unroll
-    for (int p = 0; p < kSplitPairs; ++p)
-        if (p < P) S4[(wave * kSplitPairs + p) * 64 + lane] = acc[p];
-    lds_barrier();
-    if (wave < P) {
-        floatx4 r = floatx4{my_bias, my_bias, my_bias, my_bias};
-        for (int w = 0; w < kWaves; ++w) r += S4[(w * kSplitPairs + wave) * 64 + lane];
-        epi(my_rt, my_nb, r, pf);
-    }
-}
-
-// Each wave owns column blocks nb = wave, wave+kWaves, ...; two are kept in flight where two exist (independent
-// MFMA chains: 16x16x4 f32 issues every 32 cycles but a dependent one needs 40), the odd last one runs alone.
-// epi(rt, nb, acc): lane holds out[row = 16*rt + 4*(lane>>4) + r][col = nb*16 + (lane&15)], r = 0..3.
-template <int RT, int NSEG, class Pre, class Epi>
-__device__ __forceinline__ void tile_linear_pre(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Pre&& pre,
-                                                Epi&& epi, float* __restrict__ scratch = nullptr, int sb = -1) {
-    const int wave = bd_wave(bd_tid());
-    const int Nb = (N + 15) >> 4;
-    if (scratch != nullptr && Nb * RT <= kSplitPairs) {   // workgroup-uniform
-        tile_linear_splitk<RT, NSEG>(seg, bias, N, scratch, pre, epi);
-        return;
-    }
-#ifndef BD_PIPE_D
-#define BD_PIPE_D 2
-#endif
-    constexpr int D = BD_PIPE_D;      // K blocks per register set of the software pipeline (two sets); measured on
-                                      // MI355X after the kernels became spill-free: D = 3 / 4 are 4-6 % slower than 2
-    for (int nb0 = wave; nb0 < Nb; nb0 += 2 * kWaves) {
-        if (nb0 + kWaves < Nb) linear_blocks<NSEG, RT, 2, D>(seg, bias, N, nb0, pre, epi, sb);
-        else linear_blocks<NSEG, RT, 1, D>(seg, bias, N, nb0, pre, epi, sb);
-    }
-}
-
-template <int RT, int NSEG, class Epi>
-__device__ __forceinline__ void tile_linear_g(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Epi&& epi,
-                                              float* __restrict__ scratch = nullptr, int sb = -1) {
-    tile_linear_pre<RT, NSEG>(seg, bias, N, NoPre{}, [&](int rt, int nb, floatx4 acc, NoPreVal) { epi(rt, nb, acc); },
-                              scratch, sb);
-}
-
-// single-segment convenience forms
-template <int RT, class Epi>
-__device__ __forceinline__ void tile_linear(const float* __restrict__ X, int Kb, const float* __restrict__ Wp,
-                                            const float* __restrict__ bias, int N, Epi&& epi,
-                                            float* __restrict__ scratch = nullptr) {
-    const Seg seg[1] = {{X, Wp, Kb}};
-    tile_linear_g<RT, 1>(seg, bias, N, epi, scratch);
-}
-
-template <int NSEG, class Epi>
-__device__ __forceinline__ void tile_linear_seg(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
-                                                Epi&& epi, float* __restrict__ scratch = nullptr, int sb = -1) {
-    tile_linear_g<1, NSEG>(seg, bias, N, [&](int, int nb, floatx4 acc) { epi(nb, acc); }, scratch, sb);
-}
-
-// ---- tall workgroups: RT row tiles, balanced (row tile, column block) pairs, epilogue deferred -----------------
-// A 200-wide layer has 13 column blocks; handing whole blocks to 4 waves gives 4+3+3+3, i.e. the matrix pipe of three
-// SIMDs idles for a quarter of every sweep.  With RT row tiles per workgroup the unit of work is the (row tile, block)
-// pair: every wave takes the blocks wave, wave+4, ... of ALL row tiles (`per` = Nb / kWaves of them: one weight
-// fragment feeds RT MFMAs, one activation fragment feeds `per`), and the RT pairs of each leftover block go round-robin
-// over the waves, one at most per wave (13 blocks, RT = 3: 9 + 1 pairs on three waves, 9 on the fourth).
-// The accumulators stay in registers across a workgroup barrier (TallAcc) so the layer's output can overwrite its
-// input in LDS: one image per workgroup instead of two, which is what lets three 48-row workgroups share a CU.
-constexpr int kTallMaxPer = 3;    // column blocks per wave in the main part (N <= 15 blocks + leftover rule, host-checked)
-
-template <int RT>
-struct TallAcc {
-    floatx4 main[kTallMaxPer][RT];
-    floatx4 left;
-};
-
-__host__ __device__ __forceinline__ bool tall_shape_ok(int N, int RT) {
-    const int Nb = (N + 15) >> 4, per = Nb / kWaves;
-    return per <= kTallMaxPer && (Nb - per * kWaves) * RT <= kWaves;
+    return b;
 }
 
 // TR: the two MFMA operands change places, D^T = W X^T.  The registers are the same ones (a weight fragment is a valid A
@@ -591,6 +396,191 @@ __device__ __forceinline__ void linear_sweep(const Seg (&seg)[NSEG], int nb0, fl
     if constexpr (kSplit) acc[0][0] += acc2;
 }
 
+// NI column blocks nb0, nb0+kWaves, ... of this wave (all valid), RT row tiles, all segments.
+template <int NSEG, int RT, int NI, int D, bool TR = false, class Pre, class Epi>
+__device__ __forceinline__ void linear_blocks(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, int nb0,
+                                              Pre&& pre, Epi&& epi, int sb = -1) {
+    const int lane = bd_tid() & 63;
+    BD_DSTAMP(sb, 0);
+    decltype(pre(0, 0)) pf[NI][RT];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) pf[i][rt] = pre(rt, nb0 + i * kWaves);
+    floatx4 acc[NI][RT];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        floatx4 b4;
+        if constexpr (TR) {
+            b4 = tall_bias(bias, N, nb0 + i * kWaves, lane);
+        } else {
+            const int col = (nb0 + i * kWaves) * 16 + (lane & 15);
+            const float b = (bias != nullptr && col < N) ? bias[col] : 0.f;
+            b4 = floatx4{b, b, b, b};
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[i][rt] = b4;
+    }
+    BD_DSTAMP(sb, 1);
+    linear_sweep<NSEG, RT, NI, D, TR>(seg, nb0, acc);
+    BD_DSTAMP(sb, 2);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) epi(rt, nb0 + i * kWaves, acc[i][rt], pf[i][rt]);
+    BD_DSTAMP(sb, 3);
+}
+
+// ---- split-K over waves for narrow outputs ----------------------------------------------------------------
+// When a layer has at most two (column block, row tile) pairs (N <= 32: the mean/std heads, the N=1 heads of the
+// reward/value chains, the d/d(state|action) of the embed layer) the column-block decomposition leaves all but
+// one or two waves idle while those walk every K block in sequence: ~one L2 round trip per block pair.  Here
+// every wave takes the K blocks kb = wave, wave+kWaves, ... of ALL pairs, partial accumulators meet in an LDS
+// scratch ([kWaves][pairs][64 lanes] float4) and the first `pairs` waves sum them in fixed order (deterministic)
+// and run the epilogue.  Costs one extra barrier, removes ~Kb/kWaves round trips from the step's critical path.
+constexpr int kSplitPairs = 2;
+constexpr int kHeadMaxN = 64;                                   // widest Gaussian head tile_dual_head_elem spreads
+constexpr int kHeadPlainFloats = 2 * 16 * kHeadMaxN;            // [2][16 rows][<= 64 columns] behind the partials
+constexpr int kSplitPartialFloats = kWaves * kSplitPairs * 2 * kFragFloats;   // dual form needs 2 outputs per pair
+constexpr int kSplitScratchFloats = kSplitPartialFloats + kHeadPlainFloats;
+
+template <int RT, int NSEG, bool TR = false, class Pre, class Epi>
+__device__ __forceinline__ void tile_linear_splitk(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
+                                                   float* __restrict__ scratch, Pre&& pre, Epi&& epi) {
+    const int lane = bd_tid() & 63, wave = bd_wave(bd_tid());
+    const int Nb = (N + 15) >> 4;
+    const int P = Nb * RT;                      // <= kSplitPairs (checked by the caller)
+    // the reducing waves fetch their bias and epilogue operands up front
+    const int my_nb = wave / RT, my_rt = wave - my_nb * RT;
+    decltype(pre(0, 0)) pf{};
+    floatx4 my_bias = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (wave < P) {
+        pf = pre(my_rt, my_nb);
+        if constexpr (TR) {
+            my_bias = tall_bias(bias, N, my_nb, lane);
+        } else {
+            const int col = my_nb * 16 + (lane & 15);
+            const float b = (bias != nullptr && col < N) ? bias[col] : 0.f;
+            my_bias = floatx4{b, b, b, b};
+        }
+    }
+    floatx4 acc[kSplitPairs];
+#pragma unroll
+    for (int p = 0; p < kSplitPairs; ++p) acc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // A wave's share is tiny (<= 2 K blocks x <= 2 pairs per segment for K <= 16*kWaves): issue ALL its loads
+    // before the first MFMA, so the share costs one L2 round trip instead of one per (k block, pair).
+    constexpr int KW = 2;
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        const int Kb = seg[s].Kb;
+        const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(seg[s].X) + lane;
+        const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(seg[s].W) + lane;
+        for (int kb0 = wave; kb0 < Kb; kb0 += kWaves * KW) {
+            floatx4 xa[KW][kSplitPairs], wb[KW][kSplitPairs];
+#pragma unroll
+            for (int i = 0; i < KW; ++i) {
+                const int kb = kb0 + i * kWaves;
+#pragma unroll
+                for (int p = 0; p < kSplitPairs; ++p) {
+                    if (kb < Kb && p < P) {
+                        const int nb = p / RT, rt = p % RT;
+                        xa[i][p] = X4[(rt * Kb + kb) * 64];
+                        wb[i][p] = W4[((size_t)nb * Kb + kb) * 64];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < KW; ++i) {
+                const int kb = kb0 + i * kWaves;
+#pragma unroll
+                for (int p = 0; p < kSplitPairs; ++p) {
+                    if (kb < Kb && p < P) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[p] = TR ? mfma16(wb[i][p][j], xa[i][p][j], acc[p]) : mfma16(xa[i][p][j], wb[i][p][j], acc[p]);
+                    }
+                }
+            }
+        }
+    }
+    floatx4* __restrict__ S4 = reinterpret_cast<floatx4*>(scratch);
+#pragma unroll
+    for (int p = 0; p < kSplitPairs; ++p)
+        if (p < P) S4[(wave * kSplitPairs + p) * 64 + lane] = acc[p];
+    lds_barrier();
+    if (wave < P) {
+        floatx4 r = my_bias;
+        for (int w = 0; w < kWaves; ++w) r += S4[(w * kSplitPairs + wave) * 64 + lane];
+        epi(my_rt, my_nb, r, pf);
+    }
+}
+
+// Each wave owns column blocks nb = wave, wave+kWaves, ...; two are kept in flight where two exist (independent
+// MFMA chains: 16x16x4 f32 issues every 32 cycles but a dependent one needs 40), the odd last one runs alone.
+// epi(rt, nb, acc): lane holds out[row = 16*rt + 4*(lane>>4) + r][col = nb*16 + (lane&15)], r = 0..3.
+template <int RT, int NSEG, bool TR = false, class Pre, class Epi>
+__device__ __forceinline__ void tile_linear_pre(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Pre&& pre,
+                                                Epi&& epi, float* __restrict__ scratch = nullptr, int sb = -1) {
+    const int wave = bd_wave(bd_tid());
+    const int Nb = (N + 15) >> 4;
+    if (scratch != nullptr && Nb * RT <= kSplitPairs) {   // workgroup-uniform
+        tile_linear_splitk<RT, NSEG, TR>(seg, bias, N, scratch, pre, epi);
+        return;
+    }
+#ifndef BD_PIPE_D
+#define BD_PIPE_D 2
+#endif
+    constexpr int D = BD_PIPE_D;      // K blocks per register set of the software pipeline (two sets); measured on
+                                      // MI355X after the kernels became spill-free: D = 3 / 4 are 4-6 % slower than 2
+    for (int nb0 = wave; nb0 < Nb; nb0 += 2 * kWaves) {
+        if (nb0 + kWaves < Nb) linear_blocks<NSEG, RT, 2, D, TR>(seg, bias, N, nb0, pre, epi, sb);
+        else linear_blocks<NSEG, RT, 1, D, TR>(seg, bias, N, nb0, pre, epi, sb);
+    }
+}
+
+template <int RT, int NSEG, class Epi>
+__device__ __forceinline__ void tile_linear_g(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Epi&& epi,
+                                              float* __restrict__ scratch = nullptr, int sb = -1) {
+    tile_linear_pre<RT, NSEG>(seg, bias, N, NoPre{}, [&](int rt, int nb, floatx4 acc, NoPreVal) { epi(rt, nb, acc); },
+                              scratch, sb);
+}
+
+// single-segment convenience forms
+template <int RT, class Epi>
+__device__ __forceinline__ void tile_linear(const float* __restrict__ X, int Kb, const float* __restrict__ Wp,
+                                            const float* __restrict__ bias, int N, Epi&& epi,
+                                            float* __restrict__ scratch = nullptr) {
+    const Seg seg[1] = {{X, Wp, Kb}};
+    tile_linear_g<RT, 1>(seg, bias, N, epi, scratch);
+}
+
+template <int NSEG, class Epi>
+__device__ __forceinline__ void tile_linear_seg(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
+                                                Epi&& epi, float* __restrict__ scratch = nullptr, int sb = -1) {
+    tile_linear_g<1, NSEG>(seg, bias, N, [&](int, int nb, floatx4 acc) { epi(nb, acc); }, scratch, sb);
+}
+
+// ---- tall workgroups: RT row tiles, balanced (row tile, column block) pairs, epilogue deferred -----------------
+// A 200-wide layer has 13 column blocks; handing whole blocks to 4 waves gives 4+3+3+3, i.e. the matrix pipe of three
+// SIMDs idles for a quarter of every sweep.  With RT row tiles per workgroup the unit of work is the (row tile, block)
+// pair: every wave takes the blocks wave, wave+4, ... of ALL row tiles (`per` = Nb / kWaves of them: one weight
+// fragment feeds RT MFMAs, one activation fragment feeds `per`), and the RT pairs of each leftover block go round-robin
+// over the waves, one at most per wave (13 blocks, RT = 3: 9 + 1 pairs on three waves, 9 on the fourth).
+// The accumulators stay in registers across a workgroup barrier (TallAcc) so the layer's output can overwrite its
+// input in LDS: one image per workgroup instead of two, which is what lets three 48-row workgroups share a CU.
+constexpr int kTallMaxPer = 3;    // column blocks per wave in the main part (N <= 15 blocks + leftover rule, host-checked)
+
+template <int RT>
+struct TallAcc {
+    floatx4 main[kTallMaxPer][RT];
+    floatx4 left;
+};
+
+__host__ __device__ __forceinline__ bool tall_shape_ok(int N, int RT) {
+    const int Nb = (N + 15) >> 4, per = Nb / kWaves;
+    return per <= kTallMaxPer && (Nb - per * kWaves) * RT <= kWaves;
+}
+
 // pair owned by this wave among the leftover blocks: returns false when it has none
 __device__ __forceinline__ bool tall_left_pair(int Nb, int RT, int wave, int& rt, int& nb) {
     const int per = Nb / kWaves, nleft = (Nb - per * kWaves) * RT;
@@ -599,19 +589,6 @@ __device__ __forceinline__ bool tall_left_pair(int Nb, int RT, int wave, int& rt
     rt = wave - lb * RT;
     nb = per * kWaves + lb;
     return true;
-}
-
-// Accumulators in the transposed form (linear_sweep<..., TR = true>): lane holds row lane&15, columns
-// nb*16 + 4*(lane>>4) + r.  N % 4 == 0 (host-checked by the tall chain launchers); the bias vector sits at an arbitrary
-// float offset of the flat parameter buffer, so it is read with scalar loads.
-__device__ __forceinline__ floatx4 tall_bias(const float* __restrict__ bias, int N, int nb, int lane) {
-    const int col0 = nb * 16 + 4 * (lane >> 4);
-    floatx4 b = floatx4{0.f, 0.f, 0.f, 0.f};
-    if (bias != nullptr && col0 < N) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b[r] = bias[col0 + r];
-    }
-    return b;
 }
 
 template <int RT, int NSEG>

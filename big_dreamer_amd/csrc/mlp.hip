@@ -11,7 +11,6 @@ namespace bd {
 template <int RT>
 __global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, int KbA, int KbB) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63;
     const int row0 = blockIdx.x * 16 * RT;
     float* cur = smem;                                   // inputs of even layers
     float* nxt = smem + (size_t)RT * KbA * kFragFloats;  // inputs of odd layers
@@ -41,23 +40,38 @@ __global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, in
         }
     }
     lds_barrier();
+    // Transposed accumulators (bd_device.h, linear_sweep<TR>): a lane holds row lane&15, columns nb*16 + 4*(lane>>4) + r, so
+    // the next layer's fragment tile takes one ds_write_b128 per block and the saved activations one 16-byte store where the
+    // width and the buffer allow it (4 | N, 16-byte aligned base); the scalar path serves narrow / odd layers.
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     for (int l = 0; l < a.n_layers; ++l) {
         const bd_layer L = a.layer[l];
         const bool last = (l == a.n_layers - 1);
         const int Kb = cdiv(L.K, 16), Nb = cdiv(L.N, 16);
         const bool gather0 = l == 0 && a.gD > 0;
-        tile_linear<RT>(cur, Kb, L.w, L.bias, L.N, [&](int rt, int nb, floatx4 acc) {
-            const int c = lane & 15, col = nb * 16 + c;
+        const bool vec = (L.N & 3) == 0 && al16(L.save) && (!last || ((a.ldo & 3) == 0 && al16(a.out)));
+        const Seg seg[1] = {{cur, L.w, Kb}};
+        tile_linear_pre<RT, 1, true>(seg, L.bias, L.N, NoPre{}, [&](int rt, int nb, floatx4 acc, NoPreVal) {
+            const int ln = bd_tid() & 63, m = ln & 15, col0 = nb * 16 + 4 * (ln >> 4);
+            const int grow = row0 + rt * 16 + m;
+            if (gather0 && col0 < L.N) acc += *reinterpret_cast<const floatx4*>(xs + (rt * 16 + m) * L.N + col0);   // N0 % 4 == 0
+            floatx4 v = acc;
+            if (L.act) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * (lane >> 4) + r;
-                const int grow = row0 + rt * 16 + row;
-                const float pre = (gather0 && col < L.N) ? acc[r] + xs[(rt * 16 + row) * L.N + col] : acc[r];
-                const float v = act_apply(L.act, pre);
-                if (!last) nxt[(rt * Nb + nb) * kFragFloats + ((c >> 2) * 16 + row) * 4 + (c & 3)] = v;
-                if (grow < a.M && col < L.N) {
-                    if (L.save) L.save[(size_t)grow * L.N + col] = v;
-                    if (last) a.out[(size_t)grow * a.ldo + col] = v;
+                for (int r = 0; r < 4; ++r) v[r] = elu(acc[r]);
+            }
+            if (!last) *reinterpret_cast<floatx4*>(nxt + ((rt * Nb + nb) * 64 + ln) * 4) = v;
+            if (grow < a.M && col0 < L.N) {
+                if (vec) {
+                    if (L.save) *reinterpret_cast<floatx4*>(L.save + (size_t)grow * L.N + col0) = v;
+                    if (last) *reinterpret_cast<floatx4*>(a.out + (size_t)grow * a.ldo + col0) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col0 + r < L.N) {
+                            if (L.save) L.save[(size_t)grow * L.N + col0 + r] = v[r];
+                            if (last) a.out[(size_t)grow * a.ldo + col0 + r] = v[r];
+                        }
                 }
             }
         }, scratch);
@@ -70,7 +84,6 @@ __global__ __launch_bounds__(kThreads) void mlp_fwd_kernel(bd_mlp_fwd_args a, in
 template <int RT>
 __global__ __launch_bounds__(kThreads) void mlp_bwd_kernel(bd_mlp_bwd_args a, int KbA, int KbB) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63;
     const int row0 = blockIdx.x * 16 * RT;
     float* cur = smem;
     float* nxt = smem + (size_t)RT * KbA * kFragFloats;
@@ -92,37 +105,48 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_kernel(bd_mlp_bwd_args a, in
         }
     }
     lds_barrier();
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     for (int l = a.n_layers - 1; l >= 1; --l) {
         const bd_layer_bwd L = a.layer[l];       // contraction over this layer's outputs (N) -> its inputs (K)
         const bd_layer_bwd P = a.layer[l - 1];   // whose outputs those inputs are
         const int Kb = cdiv(L.N, 16), Nb = cdiv(L.K, 16);
         const Seg segs[1] = {{cur, L.wt, Kb}};
-        tile_linear_pre<RT, 1>(
+        const bool vec = (P.N & 3) == 0 && al16(P.saved) && al16(P.dpre);     // transposed accumulators: 16-byte loads / stores
+        tile_linear_pre<RT, 1, true>(
             segs, nullptr, L.K,
             [&](int rt, int nb) {            // saved activations of the previous layer: in flight before the K loop
                 Pre4 p;
-                const int col = nb * 16 + (lane & 15);
+                const int ln = bd_tid() & 63, col0 = nb * 16 + 4 * (ln >> 4);
+                const int grow = row0 + rt * 16 + (ln & 15);
+                const bool in = P.act && grow < a.M && col0 < P.N;
+                if (in && vec) {
+                    const floatx4 t = *reinterpret_cast<const floatx4*>(P.saved + (size_t)grow * P.N + col0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int grow = row0 + rt * 16 + 4 * (lane >> 4) + r;
-                    p.v[r] = (P.act && grow < a.M && col < P.N) ? P.saved[(size_t)grow * P.N + col] : 1.f;
+                    for (int r = 0; r < 4; ++r) p.v[r] = t[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p.v[r] = (in && col0 + r < P.N) ? P.saved[(size_t)grow * P.N + col0 + r] : 1.f;
                 }
                 return p;
             },
             [&](int rt, int nb, floatx4 acc, const Pre4& p) {
-                const int c = lane & 15, col = nb * 16 + c;
+                const int ln = bd_tid() & 63, col0 = nb * 16 + 4 * (ln >> 4);
+                const int grow = row0 + rt * 16 + (ln & 15);
+                floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (grow < a.M && col0 < P.N) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * (lane >> 4) + r;
-                    const int grow = row0 + rt * 16 + row;
-                    float v = 0.f;
-                    if (grow < a.M && col < P.N) {
-                        v = acc[r];
-                        if (P.act) v *= elu_grad_from_out(p.v[r]);
-                        if (P.dpre) P.dpre[(size_t)grow * P.N + col] = v;
+                    for (int r = 0; r < 4; ++r)
+                        if (col0 + r < P.N) v[r] = P.act ? acc[r] * elu_grad_from_out(p.v[r]) : acc[r];
+                    if (P.dpre) {
+                        if (vec) *reinterpret_cast<floatx4*>(P.dpre + (size_t)grow * P.N + col0) = v;
+                        else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (col0 + r < P.N) P.dpre[(size_t)grow * P.N + col0 + r] = v[r];
+                        }
                     }
-                    nxt[(rt * Nb + nb) * kFragFloats + ((c >> 2) * 16 + row) * 4 + (c & 3)] = v;
                 }
+                *reinterpret_cast<floatx4*>(nxt + ((rt * Nb + nb) * 64 + ln) * 4) = v;
             },
             scratch);
         lds_barrier();
@@ -130,12 +154,14 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_kernel(bd_mlp_bwd_args a, in
     }
     if (a.din0 != nullptr || a.din1 != nullptr) {
         const bd_layer_bwd L = a.layer[0];
-        tile_linear<RT>(cur, cdiv(L.N, 16), L.wt, nullptr, L.K, [&](int rt, int nb, floatx4 acc) {
-            const int col = nb * 16 + (lane & 15);
+        const Seg segs[1] = {{cur, L.wt, cdiv(L.N, 16)}};
+        tile_linear_pre<RT, 1, true>(segs, nullptr, L.K, NoPre{}, [&](int rt, int nb, floatx4 acc, NoPreVal) {
+            const int ln = bd_tid() & 63, col0 = nb * 16 + 4 * (ln >> 4);
+            const int grow = row0 + rt * 16 + (ln & 15);
+            if (grow >= a.M) return;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int grow = row0 + rt * 16 + 4 * (lane >> 4) + r;
-                if (grow >= a.M) continue;
+                const int col = col0 + r;
                 float* p = nullptr;
                 if (col < a.w0) { if (a.din0) p = a.din0 + (size_t)grow * a.ld0 + col; }
                 else if (col < a.w0 + a.w1) { if (a.din1) p = a.din1 + (size_t)grow * a.ld1 + (col - a.w0); }
