@@ -122,10 +122,12 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                         a.action[(tn + grow) * A + col] = act;
                         mean_s[row * A + col] = mean;
                         std_s[row * A + col] = sd;
-                        if (a.sv_act_stats) {
+                        if (a.sv_act_stats) {      // slots 2, 3: mean and std for actor_entropy_kernel, which replaces them
                             float* st = a.sv_act_stats + (tn + grow) * 4 * A + col;
                             st[0] = th;
                             st[A] = sigmoidf(pre);
+                            st[2 * A] = mean;
+                            st[3 * A] = sd;
                         }
                     }
                     af[frag_idx(row, col)] = act;
@@ -136,8 +138,12 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         lds_barrier();
         BD_STAMP(5);
         BD_KARGS_FRESH(ap);
-        // ---- entropy: n_samples draws per (row, action dim); thread = (row, sample lane) ----
-        {
+        // ---- entropy: n_samples draws per (row, action dim) ----
+        // With saved actor statistics (training) the estimate is NOT on the recurrence: it needs only (mean, std) of this
+        // step, so it runs after the scan as one elementwise launch over all Hm x N rows (actor_entropy_kernel) instead of
+        // 10k cycles of every step of every tile (s_memtime stamps: 7 % of the step).  Without them (acting: one step, no
+        // backward) the estimate stays here; thread = (row, sample lane).
+        if (a.sv_act_stats == nullptr) {
             const int row = tid & 15, sl = tid >> 4;   // 16 sample lanes
             const int grow = row0 + row;
             for (int j = 0; j < A; ++j) {
@@ -160,27 +166,19 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                     p[0] = lp; p[1] = dm; p[2] = ds;
                 }
             }
-        }
-        lds_barrier();
-        for (int i = tid; i < 16 * A; i += blockDim.x) {
-            const int row = i / A, j = i - row * A, grow = row0 + row;
-            float lp = 0.f, dm = 0.f, ds = 0.f;
-            for (int w = 0; w < kWaves; ++w) {
-                const float* p = part + ((w * 16 + row) * A + j) * 3;
-                lp += p[0]; dm += p[1]; ds += p[2];
+            lds_barrier();
+            for (int i = tid; i < 16 * A; i += blockDim.x) {
+                const int row = i / A, j = i - row * A;
+                float lp = 0.f;
+                for (int w = 0; w < kWaves; ++w) lp += part[((w * 16 + row) * A + j) * 3];
+                lp_rj[i] = lp;
             }
-            lp_rj[i] = lp;
-            if (grow < a.N && a.sv_act_stats) {
-                float* st = a.sv_act_stats + (tn + grow) * 4 * A + j;
-                st[2 * A] = -dm * inv_ns;     // d entropy / d mean
-                st[3 * A] = -ds * inv_ns;     // d entropy / d std
+            lds_barrier();
+            if (tid < 16 && row0 + tid < a.N) {
+                float s = 0.f;
+                for (int j = 0; j < A; ++j) s += lp_rj[tid * A + j];
+                a.entropy[tn + row0 + tid] = -s * inv_ns;
             }
-        }
-        lds_barrier();
-        if (tid < 16 && row0 + tid < a.N) {
-            float s = 0.f;
-            for (int j = 0; j < A; ++j) s += lp_rj[tid * A + j];
-            a.entropy[tn + row0 + tid] = -s * inv_ns;
         }
         BD_STAMP(6);
         BD_KARGS_FRESH(ap);
@@ -282,6 +280,55 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
     }
 #undef a
+}
+
+// ---- entropy estimate of the imagined actions, off the recurrence -----------------------------------------------------
+// entropy[t][n] = -mean_k log p(tanh(mean + std * eps_k)) summed over the action dimensions, and its derivatives w.r.t.
+// mean and std (SampleDist.entropy / TanhBijector, src/models.py:630-733) from the (mean, std) the scan left in slots 2, 3
+// of the actor statistics; it overwrites them with d entropy / d mean, d entropy / d std for the backward scan.
+// One workgroup = 64 / A rows; lane = (row, action dim), the sixteen waves take the draws k = wave, wave + 16, ...;
+// partials are summed in fixed order (deterministic).
+constexpr int kEntParts = 16;
+__global__ __launch_bounds__(64 * kEntParts) void actor_entropy_kernel(const float* __restrict__ eps, float* __restrict__ stats,
+                                                            float* __restrict__ entropy, int Hm, int N, int A, int ns) {
+    __shared__ float red[kEntParts][64][3];
+    __shared__ float lpj[64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int rows_pb = 64 / A;
+    const int rl = lane / A, j = lane - rl * A;
+    const long row = (long)blockIdx.x * rows_pb + rl;            // index over Hm x N
+    const bool valid = rl < rows_pb && row < (long)Hm * N;
+    float lp = 0.f, dm = 0.f, ds = 0.f;
+    if (valid) {
+        const int t = (int)(row / N), n = (int)(row - (long)t * N);
+        const float* st = stats + (size_t)row * 4 * A + j;
+        const EntConst ec = entropy_const(st[2 * A], st[3 * A]);
+        const float* e0 = eps + ((size_t)t * ns * N + n) * A + j;
+        for (int k = part; k < ns; k += kEntParts) {
+            float l1, d1, d2;
+            entropy_sample(ec, e0[(size_t)k * N * A], l1, d1, d2);
+            lp += l1; dm += d1; ds += d2;
+        }
+    }
+    red[part][lane][0] = lp; red[part][lane][1] = dm; red[part][lane][2] = ds;
+    __syncthreads();
+    const float inv_ns = 1.f / (float)ns;
+    if (part == 0) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int w = 0; w < kEntParts; ++w) { a0 += red[w][lane][0]; a1 += red[w][lane][1]; a2 += red[w][lane][2]; }
+        lpj[lane] = a0;
+        if (valid) {
+            float* st = stats + (size_t)row * 4 * A + j;
+            st[2 * A] = -a1 * inv_ns;     // d entropy / d mean
+            st[3 * A] = -a2 * inv_ns;     // d entropy / d std
+        }
+    }
+    __syncthreads();
+    if (part == 0 && valid && j == 0) {
+        float s = 0.f;
+        for (int jj = 0; jj < A; ++jj) s += lpj[lane + jj];
+        entropy[row] = -s * inv_ns;
+    }
 }
 
 // ---- backward --------------------------------------------------------------------------------------------
@@ -539,6 +586,12 @@ int bd_imagine_forward(const bd_imagine_fwd_args* a, void* stream) {
     if (lds > 64 * 1024 && allow_big_lds(imagine_fwd_kernel)) return -1;
     hipLaunchKernelGGL(imagine_fwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);
     BD_CHECK_LAUNCH("bd_imagine_forward");
+    if (a->sv_act_stats != nullptr) {       // the entropy estimate of all Hm x N rows (kMaxA <= 64 action dimensions)
+        const int rows_pb = 64 / a->A;
+        hipLaunchKernelGGL(actor_entropy_kernel, dim3(cdiv(a->Hm * a->N, rows_pb)), dim3(64 * kEntParts), 0, (hipStream_t)stream,
+                           a->eps_entropy, a->sv_act_stats, a->entropy, a->Hm, a->N, a->A, a->n_samples);
+        BD_CHECK_LAUNCH("bd_imagine_forward(entropy)");
+    }
     return 0;
 }
 
