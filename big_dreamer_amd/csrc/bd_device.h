@@ -883,48 +883,99 @@ struct GruFrag {
     floatx4 ax, ah, bir, biz, bin, bhr, bhz, bhn;
 };
 
+struct GruHalfFrag {
+    floatx4 ax, ah, b0, b1;
+};
+
+// One column block of the cell: the four gate accumulators of block nb from the biases up, handed to epi.
+template <class Epi>
+__device__ __forceinline__ void gru_block(const floatx4* __restrict__ X4, const floatx4* __restrict__ H4, int Kb, int Be,
+                                          const GruW& w, int nb, int lane, Epi&& epi) {
+    const int col = nb * 16 + (lane & 15);
+    const bool ok = col < Be;
+    const float br = ok ? w.b_ih[col] + w.b_hh[col] : 0.f;
+    const float bz = ok ? w.b_ih[Be + col] + w.b_hh[Be + col] : 0.f;
+    const float bni = ok ? w.b_ih[2 * Be + col] : 0.f;
+    const float bnh = ok ? w.b_hh[2 * Be + col] : 0.f;
+    floatx4 R = floatx4{br, br, br, br}, Z = floatx4{bz, bz, bz, bz};
+    floatx4 NI = floatx4{bni, bni, bni, bni}, NH = floatx4{bnh, bnh, bnh, bnh};
+    const size_t off = (size_t)nb * Kb * 64 + lane;
+    const floatx4* __restrict__ Wir = reinterpret_cast<const floatx4*>(w.w_ir) + off;
+    const floatx4* __restrict__ Wiz = reinterpret_cast<const floatx4*>(w.w_iz) + off;
+    const floatx4* __restrict__ Win = reinterpret_cast<const floatx4*>(w.w_in) + off;
+    const floatx4* __restrict__ Whr = reinterpret_cast<const floatx4*>(w.w_hr) + off;
+    const floatx4* __restrict__ Whz = reinterpret_cast<const floatx4*>(w.w_hz) + off;
+    const floatx4* __restrict__ Whn = reinterpret_cast<const floatx4*>(w.w_hn) + off;
+    BD_GRU_PIPE(
+        Kb,
+        [&](int kb) {
+            return GruFrag{X4[kb * 64], H4[kb * 64], Wir[kb * 64], Wiz[kb * 64], Win[kb * 64],
+                           Whr[kb * 64], Whz[kb * 64], Whn[kb * 64]};
+        },
+        [&](const GruFrag& f) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                R = mfma16(f.ax[j], f.bir[j], R);
+                Z = mfma16(f.ax[j], f.biz[j], Z);
+                NI = mfma16(f.ax[j], f.bin[j], NI);
+                NH = mfma16(f.ah[j], f.bhn[j], NH);
+                R = mfma16(f.ah[j], f.bhr[j], R);
+                Z = mfma16(f.ah[j], f.bhz[j], Z);
+            }
+        });
+    epi(nb, R, Z, NI, NH);
+}
+
+// `scratch` (>= 4 x 64 float4 of LDS, optional): with 8 waves and 13 column blocks (Be = 200) the second round of blocks
+// 8..12 leaves waves 5, 6, 7 idle while the SIMD of waves 0 and 4 carries four blocks against three on the others.  The
+// three idle waves then take block 12 BY GATE -- wave 5 the reset gate (W_ir x + W_hr h), wave 6 the update gate, wave 7 the
+// two candidate products -- the four accumulators meet in `scratch`, and after one barrier wave 4 (which gave the block up)
+// runs its epilogue: 3 + 1/3 blocks on the fullest SIMD instead of 4 (312 MFMAs = 10k cycles of every step).
 template <class Epi>
 __device__ __forceinline__ void gru_tile(const float* __restrict__ X, const float* __restrict__ Hf, int Kb, int Be,
-                                         const GruW& w, Epi&& epi) {
+                                         const GruW& w, Epi&& epi, float* __restrict__ scratch = nullptr) {
     const int lane = bd_tid() & 63, wave = bd_wave(bd_tid());
     const int Nb = (Be + 15) >> 4;
     const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(X) + lane;
     const floatx4* __restrict__ H4 = reinterpret_cast<const floatx4*>(Hf) + lane;
-    for (int nb = wave; nb < Nb; nb += kWaves) {
-        const int col = nb * 16 + (lane & 15);
-        const bool ok = col < Be;
-        const float br = ok ? w.b_ih[col] + w.b_hh[col] : 0.f;
-        const float bz = ok ? w.b_ih[Be + col] + w.b_hh[Be + col] : 0.f;
-        const float bni = ok ? w.b_ih[2 * Be + col] : 0.f;
-        const float bnh = ok ? w.b_hh[2 * Be + col] : 0.f;
-        floatx4 R = floatx4{br, br, br, br}, Z = floatx4{bz, bz, bz, bz};
-        floatx4 NI = floatx4{bni, bni, bni, bni}, NH = floatx4{bnh, bnh, bnh, bnh};
-        const size_t off = (size_t)nb * Kb * 64 + lane;
-        const floatx4* __restrict__ Wir = reinterpret_cast<const floatx4*>(w.w_ir) + off;
-        const floatx4* __restrict__ Wiz = reinterpret_cast<const floatx4*>(w.w_iz) + off;
-        const floatx4* __restrict__ Win = reinterpret_cast<const floatx4*>(w.w_in) + off;
-        const floatx4* __restrict__ Whr = reinterpret_cast<const floatx4*>(w.w_hr) + off;
-        const floatx4* __restrict__ Whz = reinterpret_cast<const floatx4*>(w.w_hz) + off;
-        const floatx4* __restrict__ Whn = reinterpret_cast<const floatx4*>(w.w_hn) + off;
-        BD_GRU_PIPE(
-            Kb,
-            [&](int kb) {
-                return GruFrag{X4[kb * 64], H4[kb * 64], Wir[kb * 64], Wiz[kb * 64], Win[kb * 64],
-                               Whr[kb * 64], Whz[kb * 64], Whn[kb * 64]};
-            },
-            [&](const GruFrag& f) {
+    if (kWaves == 8 && Nb == 13 && scratch != nullptr) {        // workgroup-uniform
+        gru_block(X4, H4, Kb, Be, w, wave, lane, epi);             // blocks 0..7
+        floatx4* __restrict__ S4 = reinterpret_cast<floatx4*>(scratch);
+        if (wave < 4) {
+            gru_block(X4, H4, Kb, Be, w, wave + 8, lane, epi);     // blocks 8..11
+        } else if (wave > 4) {
+            const int nb = 12, col = nb * 16 + (lane & 15);
+            const bool ok = col < Be;
+            const int g = wave - 5;                                // 0: reset, 1: update, 2: candidate
+            const float b0 = !ok ? 0.f : (g == 2 ? w.b_ih[2 * Be + col] : w.b_ih[g * Be + col] + w.b_hh[g * Be + col]);
+            const float b1 = (ok && g == 2) ? w.b_hh[2 * Be + col] : 0.f;
+            floatx4 A0 = floatx4{b0, b0, b0, b0}, A1 = floatx4{b1, b1, b1, b1};    // x product | h product
+            const size_t off = (size_t)nb * Kb * 64 + lane;
+            const float* wx = g == 0 ? w.w_ir : (g == 1 ? w.w_iz : w.w_in);
+            const float* wh = g == 0 ? w.w_hr : (g == 1 ? w.w_hz : w.w_hn);
+            const floatx4* __restrict__ Wx = reinterpret_cast<const floatx4*>(wx) + off;
+            const floatx4* __restrict__ Wh = reinterpret_cast<const floatx4*>(wh) + off;
+            pipelined_k<2>(
+                Kb, [&](int kb) { return GruHalfFrag{X4[kb * 64], H4[kb * 64], Wx[kb * 64], Wh[kb * 64]}; },
+                [&](const GruHalfFrag& f) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    R = mfma16(f.ax[j], f.bir[j], R);
-                    Z = mfma16(f.ax[j], f.biz[j], Z);
-                    NI = mfma16(f.ax[j], f.bin[j], NI);
-                    NH = mfma16(f.ah[j], f.bhn[j], NH);
-                    R = mfma16(f.ah[j], f.bhr[j], R);
-                    Z = mfma16(f.ah[j], f.bhz[j], Z);
-                }
-            });
-        epi(nb, R, Z, NI, NH);
+                    for (int j = 0; j < 4; ++j) {
+                        A0 = mfma16(f.ax[j], f.b0[j], A0);
+                        A1 = mfma16(f.ah[j], f.b1[j], A1);
+                    }
+                });
+            if (g == 2) {
+                S4[2 * 64 + lane] = A0;       // NI
+                S4[3 * 64 + lane] = A1;       // NH
+            } else {
+                S4[g * 64 + lane] = A0 + A1;  // R or Z (bias + x product + h product)
+            }
+        }
+        lds_barrier();
+        if (wave == 4) epi(12, S4[lane], S4[64 + lane], S4[2 * 64 + lane], S4[3 * 64 + lane]);
+        return;
     }
+    for (int nb = wave; nb < Nb; nb += kWaves) gru_block(X4, H4, Kb, Be, w, nb, lane, epi);
 }
 
 // Backward of the two GRU matmuls: DX = W_ir^T dR + W_iz^T dZ + W_in^T dNI, DH = W_hr^T dR + W_hz^T dZ + W_hn^T dNH

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                     }
                 }
             }
-        });
+        }, scratch);
         BD_STAMP(9);
         lds_barrier();
         BD_STAMP(10);
