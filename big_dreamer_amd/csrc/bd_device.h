@@ -987,46 +987,90 @@ struct GruBwdFrag {
     floatx4 ar, az, ai, ah, bir, biz, bin, bhr, bhz, bhn;
 };
 
+// One output column block of the two transposed GRU products.
+template <class PF, class Epi>
+__device__ __forceinline__ void gru_bwd_block(const floatx4* __restrict__ R4, const floatx4* __restrict__ Z4,
+                                              const floatx4* __restrict__ I4, const floatx4* __restrict__ H4, int Kb,
+                                              const GruWT& w, int nb, int lane, const PF& pf, Epi&& epi) {
+    floatx4 DX = floatx4{0.f, 0.f, 0.f, 0.f}, DH = floatx4{0.f, 0.f, 0.f, 0.f};
+    floatx4 DX2 = DX, DH2 = DH;   // second chain per output: consecutive MFMAs stay independent
+    const size_t off = (size_t)nb * Kb * 64 + lane;
+    const floatx4* __restrict__ Wir = reinterpret_cast<const floatx4*>(w.wt_ir) + off;
+    const floatx4* __restrict__ Wiz = reinterpret_cast<const floatx4*>(w.wt_iz) + off;
+    const floatx4* __restrict__ Win = reinterpret_cast<const floatx4*>(w.wt_in) + off;
+    const floatx4* __restrict__ Whr = reinterpret_cast<const floatx4*>(w.wt_hr) + off;
+    const floatx4* __restrict__ Whz = reinterpret_cast<const floatx4*>(w.wt_hz) + off;
+    const floatx4* __restrict__ Whn = reinterpret_cast<const floatx4*>(w.wt_hn) + off;
+    BD_GRU_PIPE(
+        Kb,
+        [&](int kb) {
+            return GruBwdFrag{R4[kb * 64], Z4[kb * 64], I4[kb * 64], H4[kb * 64], Wir[kb * 64], Wiz[kb * 64],
+                              Win[kb * 64], Whr[kb * 64], Whz[kb * 64], Whn[kb * 64]};
+        },
+        [&](const GruBwdFrag& f) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                DX = mfma16(f.ar[j], f.bir[j], DX);
+                DH = mfma16(f.ar[j], f.bhr[j], DH);
+                DX2 = mfma16(f.az[j], f.biz[j], DX2);
+                DH2 = mfma16(f.az[j], f.bhz[j], DH2);
+                DX = mfma16(f.ai[j], f.bin[j], DX);
+                DH = mfma16(f.ah[j], f.bhn[j], DH);
+            }
+        });
+    epi(nb, DX + DX2, DH + DH2, pf);
+}
+
+struct GruBwdHalfFrag {
+    floatx4 ax, ah, bx, bh;
+};
+
+// `scratch` (>= 6 x 64 float4 of LDS, optional): as in gru_tile, with 8 waves and 13 column blocks the waves 5, 6, 7 take
+// block 12 by gate gradient (d r, d z, d n: one product into DX and one into DH each) and wave 4 sums the three pairs in
+// fixed order and runs the block's epilogue.
 template <class Pre, class Epi>
 __device__ __forceinline__ void gru_tile_bwd(const float* __restrict__ dR, const float* __restrict__ dZ,
                                              const float* __restrict__ dNI, const float* __restrict__ dNH, int Kb,
-                                             int Be, const GruWT& w, Pre&& pre, Epi&& epi) {
+                                             int Be, const GruWT& w, Pre&& pre, Epi&& epi, float* __restrict__ scratch = nullptr) {
     const int lane = bd_tid() & 63, wave = bd_wave(bd_tid());
     const int Nb = (Be + 15) >> 4;
     const floatx4* __restrict__ R4 = reinterpret_cast<const floatx4*>(dR) + lane;
     const floatx4* __restrict__ Z4 = reinterpret_cast<const floatx4*>(dZ) + lane;
     const floatx4* __restrict__ I4 = reinterpret_cast<const floatx4*>(dNI) + lane;
     const floatx4* __restrict__ H4 = reinterpret_cast<const floatx4*>(dNH) + lane;
-    for (int nb = wave; nb < Nb; nb += kWaves) {
-        const auto pf = pre(nb);      // epilogue operands in flight before the contraction
-        floatx4 DX = floatx4{0.f, 0.f, 0.f, 0.f}, DH = floatx4{0.f, 0.f, 0.f, 0.f};
-        floatx4 DX2 = DX, DH2 = DH;   // second chain per output: consecutive MFMAs stay independent
-        const size_t off = (size_t)nb * Kb * 64 + lane;
-        const floatx4* __restrict__ Wir = reinterpret_cast<const floatx4*>(w.wt_ir) + off;
-        const floatx4* __restrict__ Wiz = reinterpret_cast<const floatx4*>(w.wt_iz) + off;
-        const floatx4* __restrict__ Win = reinterpret_cast<const floatx4*>(w.wt_in) + off;
-        const floatx4* __restrict__ Whr = reinterpret_cast<const floatx4*>(w.wt_hr) + off;
-        const floatx4* __restrict__ Whz = reinterpret_cast<const floatx4*>(w.wt_hz) + off;
-        const floatx4* __restrict__ Whn = reinterpret_cast<const floatx4*>(w.wt_hn) + off;
-        BD_GRU_PIPE(
-            Kb,
-            [&](int kb) {
-                return GruBwdFrag{R4[kb * 64], Z4[kb * 64], I4[kb * 64], H4[kb * 64], Wir[kb * 64], Wiz[kb * 64],
-                                  Win[kb * 64], Whr[kb * 64], Whz[kb * 64], Whn[kb * 64]};
-            },
-            [&](const GruBwdFrag& f) {
+    if (kWaves == 8 && Nb == 13 && scratch != nullptr) {        // workgroup-uniform
+        decltype(pre(0)) pf12{};
+        if (wave == 4) pf12 = pre(12);                             // its epilogue operands: in flight through both rounds
+        gru_bwd_block(R4, Z4, I4, H4, Kb, w, wave, lane, pre(wave), epi);            // blocks 0..7
+        floatx4* __restrict__ S4 = reinterpret_cast<floatx4*>(scratch);
+        if (wave < 4) {
+            gru_bwd_block(R4, Z4, I4, H4, Kb, w, wave + 8, lane, pre(wave + 8), epi);   // blocks 8..11
+        } else if (wave > 4) {
+            const int g = wave - 5;                                // 0: d r, 1: d z, 2: d n
+            const size_t off = (size_t)12 * Kb * 64 + lane;
+            const floatx4* __restrict__ Ax = g == 0 ? R4 : (g == 1 ? Z4 : I4);
+            const floatx4* __restrict__ Ah = g == 0 ? R4 : (g == 1 ? Z4 : H4);
+            const floatx4* __restrict__ Wx = reinterpret_cast<const floatx4*>(g == 0 ? w.wt_ir : (g == 1 ? w.wt_iz : w.wt_in)) + off;
+            const floatx4* __restrict__ Wh = reinterpret_cast<const floatx4*>(g == 0 ? w.wt_hr : (g == 1 ? w.wt_hz : w.wt_hn)) + off;
+            floatx4 DX = floatx4{0.f, 0.f, 0.f, 0.f}, DH = DX;
+            pipelined_k<2>(
+                Kb, [&](int kb) { return GruBwdHalfFrag{Ax[kb * 64], Ah[kb * 64], Wx[kb * 64], Wh[kb * 64]}; },
+                [&](const GruBwdHalfFrag& f) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    DX = mfma16(f.ar[j], f.bir[j], DX);
-                    DH = mfma16(f.ar[j], f.bhr[j], DH);
-                    DX2 = mfma16(f.az[j], f.biz[j], DX2);
-                    DH2 = mfma16(f.az[j], f.bhz[j], DH2);
-                    DX = mfma16(f.ai[j], f.bin[j], DX);
-                    DH = mfma16(f.ah[j], f.bhn[j], DH);
-                }
-            });
-        epi(nb, DX + DX2, DH + DH2, pf);
+                    for (int j = 0; j < 4; ++j) {
+                        DX = mfma16(f.ax[j], f.bx[j], DX);
+                        DH = mfma16(f.ah[j], f.bh[j], DH);
+                    }
+                });
+            S4[(2 * g) * 64 + lane] = DX;
+            S4[(2 * g + 1) * 64 + lane] = DH;
+        }
+        lds_barrier();
+        if (wave == 4)
+            epi(12, S4[lane] + S4[2 * 64 + lane] + S4[4 * 64 + lane], S4[64 + lane] + S4[3 * 64 + lane] + S4[5 * 64 + lane], pf12);
+        return;
     }
+    for (int nb = wave; nb < Nb; nb += kWaves) gru_bwd_block(R4, Z4, I4, H4, Kb, w, nb, lane, pre(nb), epi);
 }
 
 // element offset inside a fragment tile for the accumulator element (row = 4*(lane>>4)+r, col = nb*16+(lane&15))

@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
                     }
                     dE[off] = de;
                 }
-            });
+            }, scratch);
         lds_barrier();
         BD_KARGS_FRESH(ap);
         // ---- 5: embed layer -> d state_t (carry) and d action_t -> actor output gradients ----

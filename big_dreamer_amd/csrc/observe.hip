@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kThreads) void observe_fwd_kernel(bd_observe_fwd_ar
                     }
                 }
             }
-        });
+        }, scratch);
         lds_barrier();
         // ---- D: posterior hidden ----
         tile_linear<1>(h_nxt, d.Kb_h, a.w_q1h, a.b_q1, a.Hd, [&](int, int nb, floatx4 acc) {
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void observe_bwd_kernel(bd_observe_bwd_ar
                     }
                     dE[off] = de;
                 }
-            });
+            }, scratch);
         lds_barrier();
         // ---- 5: d posterior_state_t through the embed layer and the nonterminal mask ----
         tile_linear<1>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kThreads) void plan_rollout_kernel(bd_plan_args a) 
                 if (col < a.Be) ff[frag_idx(row, col)] = hn;
                 if (a.feat && ok) a.feat[(tn + row0 + row) * F + col] = hn;
             }
-        });
+        }, scratch);
         lds_barrier();
         // ---- prior: s' = mean + std * eps ----
         {

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_fwd_kernel(bd_observe_ca
                     }
                 }
             }
-        });
+        }, lg);
         lds_barrier();
         CAT_STAMP(5);
         BD_KARGS_FRESH(ap);
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(kThreads) void observe_cat_bwd_kernel(bd_observe_ca
                     }
                     dE[off] = de;
                 }
-            });
+            }, pl);
         lds_barrier();
         CAT_STAMP(21);
     }
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
                     }
                 }
             }
-        });
+        }, uni);
         lds_barrier();
         BD_KARGS_FRESH(ap);
         // ---- prior hidden, logits, sample ----
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_bwd_kernel(bd_imagine_ca
                     }
                     dE[off] = de;
                 }
-            });
+            }, uni);
         lds_barrier();
         BD_KARGS_FRESH(ap);
         // ---- 5: embed layer -> d action_t -> actor output gradients (d state_t is taken by the next iteration's head) ----
