@@ -180,6 +180,8 @@ _SIGS = {
     "bd_imagine_cat_forward": (I32, [C.POINTER(ImagineCatFwdArgs), P]),
     "bd_imagine_cat_backward": (I32, [C.POINTER(ImagineCatBwdArgs), P]),
     "bd_imagine_forward": (I32, [C.POINTER(ImagineFwdArgs), P]),
+    "bd_imagine_forward_scan": (I32, [C.POINTER(ImagineFwdArgs), P]),
+    "bd_actor_entropy": (I32, [P, P, P, I32, I32, I32, I32, P]),
     "bd_imagine_backward": (I32, [C.POINTER(ImagineBwdArgs), P]),
     "bd_lambda_return_forward": (I32, [P, P, I32, I32, F32, F32, P, P]),
     "bd_dense_ws_supported": (I32, [I32, I32, I32]),

@@ -567,7 +567,7 @@ int bd_debug_dstamps(unsigned long long* out64) {
 }
 #endif
 
-int bd_imagine_forward(const bd_imagine_fwd_args* a, void* stream) {
+static int imagine_forward_scan(const bd_imagine_fwd_args* a, void* stream) {
     BD_REQUIRE(a && a->N > 0 && a->Hm > 0 && a->Be > 0 && a->S > 0 && a->A > 0 && a->A <= kMaxA && a->Hd > 0 &&
                    a->n_samples > 0, "bd_imagine_forward: bad dims");
     BD_REQUIRE(a->S <= kHeadMaxN && a->A <= kHeadMaxN, "bd_imagine_forward: state / action width above %d", kHeadMaxN);
@@ -586,12 +586,27 @@ int bd_imagine_forward(const bd_imagine_fwd_args* a, void* stream) {
     if (lds > 64 * 1024 && allow_big_lds(imagine_fwd_kernel)) return -1;
     hipLaunchKernelGGL(imagine_fwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);
     BD_CHECK_LAUNCH("bd_imagine_forward");
-    if (a->sv_act_stats != nullptr) {       // the entropy estimate of all Hm x N rows (kMaxA <= 64 action dimensions)
-        const int rows_pb = 64 / a->A;
-        hipLaunchKernelGGL(actor_entropy_kernel, dim3(cdiv(a->Hm * a->N, rows_pb)), dim3(64 * kEntParts), 0, (hipStream_t)stream,
-                           a->eps_entropy, a->sv_act_stats, a->entropy, a->Hm, a->N, a->A, a->n_samples);
-        BD_CHECK_LAUNCH("bd_imagine_forward(entropy)");
-    }
+    return 0;
+}
+
+int bd_actor_entropy(const float* eps_entropy, float* act_stats, float* entropy, int Hm, int N, int A, int n_samples,
+                     void* stream) {
+    BD_REQUIRE(eps_entropy && act_stats && entropy && Hm > 0 && N > 0 && A > 0 && A <= kMaxA && n_samples > 0,
+               "bd_actor_entropy: bad arguments");
+    const int rows_pb = 64 / A;
+    hipLaunchKernelGGL(actor_entropy_kernel, dim3(cdiv(Hm * N, rows_pb)), dim3(64 * kEntParts), 0, (hipStream_t)stream,
+                       eps_entropy, act_stats, entropy, Hm, N, A, n_samples);
+    BD_CHECK_LAUNCH("bd_actor_entropy");
+    return 0;
+}
+
+int bd_imagine_forward_scan(const bd_imagine_fwd_args* a, void* stream) { return imagine_forward_scan(a, stream); }
+
+int bd_imagine_forward(const bd_imagine_fwd_args* a, void* stream) {
+    if (int rc = imagine_forward_scan(a, stream)) return rc;
+    // with saved actor statistics the scan leaves (mean, std) in their slots 2, 3 and the estimate is one more launch
+    if (a->sv_act_stats != nullptr)
+        return bd_actor_entropy(a->eps_entropy, a->sv_act_stats, a->entropy, a->Hm, a->N, a->A, a->n_samples, stream);
     return 0;
 }
 

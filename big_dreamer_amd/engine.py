@@ -929,13 +929,13 @@ class DreamerEngine:
         H1 = Hm // 2 if (split and Hm >= 2) else 0
         with self.span("imagine_fwd"):
             if not H1:
-                cabi.check(lib.bd_imagine_forward(C.byref(a), cabi.stream()))
+                cabi.check(lib.bd_imagine_forward_scan(C.byref(a), cabi.stream()))
             else:
                 # two time segments: the frozen reward / value heads of the first can run under the second
                 # (_behaviour_phase).  Same kernel, same operands per step: bit-identical to one launch.
                 a.sv_actor_stride = Mi * d.Hd
                 a.Hm = H1
-                cabi.check(lib.bd_imagine_forward(C.byref(a), cabi.stream()))
+                cabi.check(lib.bd_imagine_forward_scan(C.byref(a), cabi.stream()))
                 self._ev_img_half = torch.cuda.Event()
                 self._ev_img_half.record(torch.cuda.current_stream())
                 r0 = H1 * N
@@ -954,7 +954,10 @@ class DreamerEngine:
                     a.sv_act_stats = a.sv_act_stats + r0 * 4 * d.A * f4
                     a.sv_x, a.sv_gates = a.sv_x + r0 * d.Be * f4, a.sv_gates + r0 * 4 * d.Be * f4
                     a.sv_p = a.sv_p + r0 * d.Hd * f4
-                cabi.check(lib.bd_imagine_forward(C.byref(a), cabi.stream()))
+                cabi.check(lib.bd_imagine_forward_scan(C.byref(a), cabi.stream()))
+        if save:        # the entropy estimate of all Hm x N rows: off the recurrence (bd_actor_entropy), outside the scan's span
+            cabi.check(lib.bd_actor_entropy(ptr(noise["entropy"]), ptr(self._buf["sv_act_stats"]), ptr(ent), Hm, N, d.A,
+                                            d.n_entropy, cabi.stream()))
         self._img_split_rows = H1 * N
         return ifeat, ent, act
 

@@ -305,6 +305,14 @@ typedef struct {
                                two time segments (second segment: Hm, start_feat and every [Hm x ...] pointer shifted) */
 } bd_imagine_fwd_args;
 int bd_imagine_forward(const bd_imagine_fwd_args* a, void* stream);
+/* The two launches of bd_imagine_forward separately (a caller that saves the actor statistics may run the entropy
+ * estimate on another stream: it is off the recurrence).  bd_imagine_forward_scan leaves (mean, std) of every action in
+ * slots 2, 3 of sv_act_stats and writes no entropy when sv_act_stats != NULL (with NULL it computes the entropy in the
+ * scan and the second call is not needed); bd_actor_entropy turns them into entropy[Hm x N] and d entropy / d mean, / d std
+ * in the same slots (SampleDist.entropy / TanhBijector, src/models.py:630-733). */
+int bd_imagine_forward_scan(const bd_imagine_fwd_args* a, void* stream);
+int bd_actor_entropy(const float* eps_entropy, float* act_stats, float* entropy, int Hm, int N, int A, int n_samples,
+                     void* stream);
 
 typedef struct {
     int N, Hm, Be, S, A, Hd;
