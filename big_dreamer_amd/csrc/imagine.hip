@@ -374,6 +374,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
             return DprePre{saved, tn_, width, a.N, row0, lane};
         };
         BD_KARGS_FRESH(ap);
+        BD_STAMP(20);
         // ---- 1: prior sample -> (mean, raw) ----
         for (int i = tid; i < 16 * d.Kb_s * 16; i += blockDim.x) {
             const int r = i / (d.Kb_s * 16), k = i - r * (d.Kb_s * 16);
@@ -389,6 +390,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
         }
         lds_barrier();
         BD_KARGS_FRESH(ap);
+        BD_STAMP(21);
         // ---- 2: prior hidden ----
         {
             const Seg segs[2] = {{dM, a.wt_p2m, d.Kb_s}, {dRaw, a.wt_p2s, d.Kb_s}};
@@ -396,6 +398,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
         }
         lds_barrier();
         BD_KARGS_FRESH(ap);
+        BD_STAMP(22);
         // ---- 3: total d belief_{t+1}; GRU gates ----
         {
             const Seg segs3[1] = {{dP, a.wt_p1, d.Kb_hd}};
@@ -444,6 +447,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
         }
         lds_barrier();
         BD_KARGS_FRESH(ap);
+        BD_STAMP(23);
         // ---- 4: through W_ih / W_hh ----
         const GruWT gw{a.wt_ir, a.wt_iz, a.wt_in, a.wt_hr, a.wt_hz, a.wt_hn};
         gru_tile_bwd(
@@ -474,6 +478,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
             }, scratch);
         lds_barrier();
         BD_KARGS_FRESH(ap);
+        BD_STAMP(24);
         // ---- 5: embed layer -> d state_t (carry) and d action_t -> actor output gradients ----
         tile_linear<1>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
@@ -530,6 +535,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
         }
         lds_barrier();
         BD_KARGS_FRESH(ap);
+        BD_STAMP(25);
         // ---- 6: actor MLP backward (input detached: no gradient below layer 0) ----
         {
             const Seg segs[2] = {{dAm, a.wt_a4m, d.Kb_a}, {dAr, a.wt_a4s, d.Kb_a}};
@@ -548,6 +554,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
                 float* tmp = src; src = dst; dst = tmp;
             }
         }
+        BD_STAMP(26);
     }
 #undef a
 }

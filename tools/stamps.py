@@ -65,3 +65,15 @@ if fn2 is not None:
     for i, n in enumerate(names):
         dt = st[i + 1] - st[i]
         print(f"  {n:34s} {dt:8d}  {100.0 * dt / tot:5.1f} %")
+
+# ---- imagination backward, workgroup 0, step t = 3 ----
+outb = (ctypes.c_ulonglong * 64)()
+assert fn(outb) == 0
+sb_ = np.array(outb[20:27], dtype=np.int64)
+if sb_[6] > sb_[0] > 0:
+    namesb = ["1 prior sample -> (mean, raw)", "2 prior hidden", "3 d belief, GRU gates", "4 through W_ih / W_hh", "5 embed layer, actor output grads",
+              "6 actor MLP backward"]
+    totb = sb_[6] - sb_[0]
+    print(f"one imagination BACKWARD step of workgroup 0: {totb} cycles")
+    for i, n in enumerate(namesb):
+        print(f"  {n:36s} {sb_[i + 1] - sb_[i]:8d}  {100.0 * (sb_[i + 1] - sb_[i]) / totb:5.1f} %")
