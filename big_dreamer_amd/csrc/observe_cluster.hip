@@ -371,6 +371,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
         const int lane = tid & 63, wave = bd_wave(tid);
         ++epoch;
         BD_KARGS_FRESH(ap);
+        BD_CSTAMP(16);
         // ---- 1: through the sample / softplus into (mean, raw) (every member) ----
         for (int i = tid; i < 16 * d.Kb_s * 16; i += blockDim.x) {
             const int r = i / (d.Kb_s * 16), k = i - r * (d.Kb_s * 16);
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
         }
         lds_barrier();
         BD_KARGS_FRESH(ap);
+        BD_CSTAMP(17);
         // ---- 2: d q (every member) ----
         {
             const Seg segs[2] = {{dM, a.wt_q2m, d.Kb_s}, {dRaw, a.wt_q2s, d.Kb_s}};
@@ -423,6 +425,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
         }
         lds_barrier();
         BD_KARGS_FRESH(ap);
+        BD_CSTAMP(18);
         // ---- 3: total d belief_{t+1}, GRU gate gradients (every member, full width) ----
         {
             const Seg segs3[1] = {{dQ, a.wt_q1h, d.Kb_hd}};
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
         }
         lds_barrier();
         BD_KARGS_FRESH(ap);
+        BD_CSTAMP(19);
         // ---- 4: through W_ih / W_hh: this member's column blocks, K split over the waves ----
         const int my_nb = c + wave * C;
         const bool reducer = wave < kLocalBlocks && my_nb < Nb;
@@ -549,6 +553,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
                 de_keep[r] = de;
             }
         }
+        BD_CSTAMP(20);
         publish(flags + c, epoch);
         if (reducer) {
             const int col = my_nb * 16 + (lane & 15);
@@ -558,10 +563,13 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
                 if (grow < a.B && col < a.Be) a.d_embed_pre[(tb + grow) * a.Be + col] = de_keep[r];
             }
         }
+        BD_CSTAMP(21);
         wait_all(flags, C, epoch, err, spin_limit, kErrBwd);
+        BD_CSTAMP(22);
         gather_payload(xbuf + (size_t)(epoch & 1) * (2 * nh), dhc, 2 * nh);
         lds_barrier();
         BD_KARGS_FRESH(ap);
+        BD_CSTAMP(23);
         // ---- 5: d posterior_state_t through the embed layer and the nonterminal mask (every member) ----
         tile_linear<1>(dE, d.Kb_h, a.wt_embed_s, nullptr, a.S, [&](int, int nb, floatx4 acc) {
             const int col = nb * 16 + (lane & 15);
@@ -576,6 +584,7 @@ __global__ __launch_bounds__(kThreads) void observe_cbwd_kernel(bd_observe_bwd_a
             }
         }, scratch);
         lds_barrier();
+        BD_CSTAMP(24);
     }
 #undef a
 }

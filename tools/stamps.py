@@ -77,3 +77,16 @@ if sb_[6] > sb_[0] > 0:
     print(f"one imagination BACKWARD step of workgroup 0: {totb} cycles")
     for i, n in enumerate(namesb):
         print(f"  {n:36s} {sb_[i + 1] - sb_[i]:8d}  {100.0 * (sb_[i + 1] - sb_[i]) / totb:5.1f} %")
+
+# ---- cluster observe scan (backward), member 0 of tile 0, step 5 ----
+if fn2 is not None:
+    outc = (ctypes.c_ulonglong * 64)()
+    assert fn2(outc) == 0
+    cb = np.array(outc[16:25], dtype=np.int64)
+    if cb[8] > cb[0] > 0:
+        namesc = ["1 sample / softplus -> (mean, raw)", "2 d q", "3 d belief, GRU gate grads (full)", "4 W_ih / W_hh, member's blocks (split-K)",
+                  "publish", "wait_all", "gather payload", "5 d state through the embed layer"]
+        totc = cb[8] - cb[0]
+        print(f"one observe BACKWARD step (cluster, member 0): {totc} cycles")
+        for i, n in enumerate(namesc):
+            print(f"  {n:44s} {cb[i + 1] - cb[i]:8d}  {100.0 * (cb[i + 1] - cb[i]) / totc:5.1f} %")
