@@ -196,9 +196,12 @@ def run_workload(d, pixel, args, rank, world, dev, dist_on, steps, warmup, timer
     return dt, kt, logs, eng
 
 
-def surface_ms_per_step(d, dev, steps, warmup, burst=5):
+def surface_ms_per_step(d, dev, steps, warmup, bursts_of=(5, 50)):
     """The same workload through the reference's call surface: ``Dreamer(params, env).train_step()`` in bursts of
-    `burst` = collect_interval steps, reading the LAST log dict of each burst as src/main.py:103-108 does."""
+    collect_interval steps, reading the LAST log dict of each burst as src/main.py:103-108 does.  One agent, timed with
+    every burst length of `bursts_of` (5 = the reference's config default, 50 = its README's example command).
+    Returns ({burst: ms per step}, last logs)."""
+    import gc
     from big_dreamer_amd import synth
     from big_dreamer_amd.config import load_config
     from big_dreamer_amd.dreamer import Dreamer
@@ -216,20 +219,40 @@ def surface_ms_per_step(d, dev, steps, warmup, burst=5):
         getattr(agent.buffer, k)[:] = v
     agent.buffer.idx, agent.buffer.full = 0, True
     agent.buffer.sync_device()
+    gc.collect()
+    gc.freeze()          # as for the engine timing: a generation-2 collection stalls the enqueueing thread for ~40 ms
     logs = None
-    for _ in range(warmup):
+    # (the replay hands out batches from a ring of four buffers and the features are double-buffered by step parity: the
+    # weight-gradient descriptor tables are built once per operand-pointer set, with a synchronising H2D copy each)
+    for _ in range(max(warmup, 12)):
         logs = agent.train_step()
     float(logs["model_loss"])
     torch.cuda.synchronize()
-    bursts = max(1, steps // burst)
-    t0 = time.perf_counter()
-    for _ in range(bursts):
-        for _ in range(burst):
-            logs = agent.train_step()
-        float(logs["model_loss"])            # the loop reads the burst's last dict (weight_update_per_sec, logging)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return dt / (bursts * burst) * 1e3, {k: round(float(v), 5) for k, v in logs.items()}
+    res = {}
+    for burst in bursts_of:
+        bursts = max(1, steps // burst)
+        t0 = time.perf_counter()
+        for _ in range(bursts):
+            for _ in range(burst):
+                logs = agent.train_step()
+            float(logs["model_loss"])            # the loop reads the burst's last dict (weight_update_per_sec, logging)
+        torch.cuda.synchronize()
+        res[burst] = (time.perf_counter() - t0) / (bursts * burst) * 1e3
+    return res, {k: round(float(v), 5) for k, v in logs.items()}
+
+
+def child_json(extra_args, timeout=600):
+    """Run this script again as a CHILD process (fresh HIP context and streams) and return the JSON object it prints.
+    A second engine built in a process that has already run one is measured 10-15 % slow (3.65 against 3.2 ms/step for
+    the surface leg, 16.0 against 15.7 for the pixel leg): the legs of the default run are therefore separate processes,
+    one after the other, while this one holds no engine."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(extra_args)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    if r.returncode != 0:
+        raise RuntimeError(f"child {' '.join(extra_args)} failed ({r.returncode}):\n{r.stderr[-2000:]}")
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
 def main():
@@ -239,6 +262,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the surface and pixel-config legs (profiling runs)")
+    ap.add_argument("--surface-only", action="store_true", help=argparse.SUPPRESS)    # child process of the default run
     ap.add_argument("--pixel", action="store_true",
                     help="BASELINE.json configs[2] (64x64 pixel observations, action dim 17) instead of the default configs[1]")
     ap.add_argument("--categorical", choices=["pixel", "state"], default=None,
@@ -254,6 +278,13 @@ def main():
         # plain `python bench.py --gpus N`: become the launcher -- N fresh rank processes of this script, one per GPU;
         # this parent never touches HIP.  Rank 0 prints the JSON line.
         sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+
+    if args.surface_only:       # child of the default run: the workload through Dreamer.train_step, nothing else in the process
+        from big_dreamer_amd import synth
+        torch.cuda.set_device(0)
+        res, slogs = surface_ms_per_step(synth.CONFIG2, torch.device("cuda", 0), args.steps, args.warmup)
+        print(json.dumps({"ms_per_step": res, "losses": slogs}), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
@@ -341,30 +372,23 @@ def main():
     del eng
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_secondary and not args.pixel and not args.categorical:
-        # (a) the same workload through the reference's call surface (Dreamer.train_step, lazy log dicts)
-        sms, slogs = surface_ms_per_step(d, dev, args.steps, args.warmup)
+        # (a) the same workload through the reference's call surface (Dreamer.train_step, lazy log dicts): child process
+        sc = child_json(["--surface-only", "--steps", str(args.steps), "--warmup", str(args.warmup)])
+        sms = sc["ms_per_step"]["5"]
         out["surface_ms_per_step"] = sms
         out["surface"] = {"ms_per_step": sms, "value": d.transitions_per_step / (sms * 1e-3),
-                          "how": "Dreamer(params, env).train_step() in bursts of collect_interval=5, last log dict of each "
-                                 "burst read (src/main.py:103-108); `value`/`ms_per_step` above drive the engine directly",
-                          "losses": slogs}
-        torch.cuda.empty_cache()
-        # (b) BASELINE.json configs[2] (pixels, A=17) in the same process: its step time and the roofline of ITS
-        #     dominant kernel, the decoder's grouped weight-gradient GEMM (bench.py --pixel makes it the main line)
-        d3 = synth.CONFIG3
+                          "ms_per_step_burst50": sc["ms_per_step"].get("50"),
+                          "how": "Dreamer(params, env).train_step() in bursts of collect_interval=5 (burst50: 50, the reference "
+                                 "README's example), last log dict of each burst read (src/main.py:103-108), in its own process; "
+                                 "`value`/`ms_per_step` above drive the engine directly",
+                          "losses": sc["losses"]}
+        # (b) BASELINE.json configs[2] (pixels, A=17): its step time and the roofline of ITS dominant kernel, the decoder's
+        #     grouped weight-gradient GEMM -- the line `bench.py --pixel` prints, from a child process
         psteps = max(5, min(20, args.steps))
-        pdt, pkt, plogs, peng = run_workload(d3, True, args, rank, world, dev, False, psteps, 3)
-        out["secondary"] = {
-            "workload": "BASELINE.json configs[2]: 64x64 pixel-obs Dreamer train_step, conv encoder/decoder on this "
-                        "library's gather-GEMM kernels, action=17, batch=50 chunk=50 H=15",
-            "value": d3.transitions_per_step * psteps / pdt, "unit": "latent transitions/s",
-            "ms_per_step": pdt / psteps * 1e3, "steps": psteps, "warmup": 3,
-            "roofline": pixel_roofline(d3, pkt),
-            "kernel_ms": {k: round(v[0], 4) for k, v in pkt.items()},
-            "losses": {k: round(v, 5) for k, v in plogs.items()},
-        }
-        del peng
-        torch.cuda.empty_cache()
+        pc = child_json(["--pixel", "--no-secondary", "--no-cpu-baseline", "--steps", str(psteps), "--warmup", "3"])
+        out["secondary"] = {"workload": pc["config"]["workload"], "value": pc["value"], "unit": pc["unit"],
+                            "ms_per_step": pc["ms_per_step"], "steps": pc["steps"], "warmup": pc["warmup"],
+                            "roofline": pc["roofline"], "kernel_ms": pc["kernel_ms"], "losses": pc["losses"]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d)
