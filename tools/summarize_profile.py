@@ -4,11 +4,17 @@ FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), <tag>_README.m
 <tag>_pixel_bench.json, <tag>_pixel_kernel_stats.csv, <tag>_pixel_traffic.json (configs[2]: conv / weight-gradient kernels)."""
 import collections
 import csv
-import glob
+import glob as _glob
 import json
 import os
 import shutil
 import sys
+
+
+class glob:      # newest first: a tag's directory may hold the files of more than one run of a leg
+    @staticmethod
+    def glob(pattern):
+        return sorted(_glob.glob(pattern), key=os.path.getmtime, reverse=True)
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
