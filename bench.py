@@ -373,22 +373,30 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_secondary and not args.pixel and not args.categorical:
         # (a) the same workload through the reference's call surface (Dreamer.train_step, lazy log dicts): child process
-        sc = child_json(["--surface-only", "--steps", str(args.steps), "--warmup", str(args.warmup)])
-        sms = sc["ms_per_step"]["5"]
-        out["surface_ms_per_step"] = sms
-        out["surface"] = {"ms_per_step": sms, "value": d.transitions_per_step / (sms * 1e-3),
-                          "ms_per_step_burst50": sc["ms_per_step"].get("50"),
-                          "how": "Dreamer(params, env).train_step() in bursts of collect_interval=5 (burst50: 50, the reference "
-                                 "README's example), last log dict of each burst read (src/main.py:103-108), in its own process; "
-                                 "`value`/`ms_per_step` above drive the engine directly",
-                          "losses": sc["losses"]}
+        try:
+            sc = child_json(["--surface-only", "--steps", str(args.steps), "--warmup", str(args.warmup)])
+            sms = sc["ms_per_step"]["5"]
+            out["surface_ms_per_step"] = sms
+            out["surface"] = {"ms_per_step": sms, "value": d.transitions_per_step / (sms * 1e-3),
+                              "ms_per_step_burst50": sc["ms_per_step"].get("50"),
+                              "how": "Dreamer(params, env).train_step() in bursts of collect_interval=5 (burst50: 50, the "
+                                     "reference README's example), last log dict of each burst read (src/main.py:103-108), in "
+                                     "its own process; `value`/`ms_per_step` above drive the engine directly",
+                              "losses": sc["losses"]}
+        except Exception as e:          # a leg that fails must not take the headline line with it
+            log(f"surface leg failed: {e}")
+            out["surface"] = {"error": str(e)[-500:]}
         # (b) BASELINE.json configs[2] (pixels, A=17): its step time and the roofline of ITS dominant kernel, the decoder's
         #     grouped weight-gradient GEMM -- the line `bench.py --pixel` prints, from a child process
         psteps = max(5, min(20, args.steps))
-        pc = child_json(["--pixel", "--no-secondary", "--no-cpu-baseline", "--steps", str(psteps), "--warmup", "3"])
-        out["secondary"] = {"workload": pc["config"]["workload"], "value": pc["value"], "unit": pc["unit"],
-                            "ms_per_step": pc["ms_per_step"], "steps": pc["steps"], "warmup": pc["warmup"],
-                            "roofline": pc["roofline"], "kernel_ms": pc["kernel_ms"], "losses": pc["losses"]}
+        try:
+            pc = child_json(["--pixel", "--no-secondary", "--no-cpu-baseline", "--steps", str(psteps), "--warmup", "3"])
+            out["secondary"] = {"workload": pc["config"]["workload"], "value": pc["value"], "unit": pc["unit"],
+                                "ms_per_step": pc["ms_per_step"], "steps": pc["steps"], "warmup": pc["warmup"],
+                                "roofline": pc["roofline"], "kernel_ms": pc["kernel_ms"], "losses": pc["losses"]}
+        except Exception as e:
+            log(f"pixel leg failed: {e}")
+            out["secondary"] = {"error": str(e)[-500:]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d)

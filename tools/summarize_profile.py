@@ -107,7 +107,7 @@ if os.path.exists(os.path.join(src, "bench.json")):
     stats_table(readme, rows)
     readme.write("\nHIP-event averages inside bench.py (ms): " + json.dumps(bench["kernel_ms"]) + "\n\n")
     table(readme, traffic)
-    if "secondary" in bench:
+    if "secondary" in bench and "error" not in bench["secondary"]:
         s2 = bench["secondary"]
         readme.write(f"\nSecondary record of the same run (configs[2], pixels): {s2['ms_per_step']:.2f} ms/step, "
                      f"{s2['value']:.0f} transitions/s; decoder weight-gradient GEMM {s2['roofline']['avg_launch_ms']:.3f} ms/launch = "
