@@ -51,18 +51,6 @@ __device__ __forceinline__ int bd_tid() {
 static_assert((kWaves & (kWaves - 1)) == 0, "kWaves must be a power of two");
 __device__ __forceinline__ int bd_wave(int tid) { return ((tid >> 6) + (int)blockIdx.x) & (kWaves - 1); }
 
-// Wave priority around non-MFMA sections.  A wave whose SIMD-mates stream MFMAs gets roughly one issue slot per MFMA of
-// theirs (32 cycles): a 300-instruction epilogue that takes 5.7k cycles alone took 16-33k next to two sweeping waves, the
-// four DMA instructions of a weight-gradient stage 1.2-1.5k (s_memtime stamps).  Raised priority lets the short
-// VALU / memory section through; the MFMA streams lose a few issue slots.  -DBD_NO_PRIO compiles them out.
-#ifdef BD_NO_PRIO
-#define BD_PRIO_HI()
-#define BD_PRIO_LO()
-#else
-#define BD_PRIO_HI() __builtin_amdgcn_s_setprio(3)
-#define BD_PRIO_LO() __builtin_amdgcn_s_setprio(0)
-#endif
-
 // Kernel arguments re-read from the kernarg segment.  The scan kernels take ~60 pointers: kept live across the time loop
 // they exceed the 102 SGPRs and hipcc spills them into VGPR lanes -- v_writelane / v_readlane were 1 600 of the 4 800
 // VALU instructions of the imagination forward kernel, executed on the SIMD that should be issuing MFMAs (fp32 MFMA and

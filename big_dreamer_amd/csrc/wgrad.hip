@@ -408,9 +408,7 @@ __device__ __forceinline__ void wgrad_dense_body(const bd_wgrad_desc& d, float* 
         const bool more = st + 2 < nst;
         [[maybe_unused]] const int sb = (st == 10 || st == 11) ? (st - 10) * 8 : -1;   // diagnostic stamps (-DBD_STAMPS)
         BD_DSTAMP(sb, 0);
-        BD_PRIO_HI();
         if (more) issue(wlds + ((st + 2) % kWRing) * kWStage, m_begin + (st + 2) * kWRows);
-        BD_PRIO_LO();
         BD_DSTAMP(sb, 1);
         const float* Pb = buf + lrow * kWLd + my_nb0 * 16 + lcol;
         const float* Ab = buf + kWRows * kWLd + lrow * kWLd + my_kb0 * 16 + lcol;
