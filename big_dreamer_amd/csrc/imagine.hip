@@ -537,6 +537,11 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
         BD_KARGS_FRESH(ap);
         BD_STAMP(25);
         // ---- 6: actor MLP backward (input detached: no gradient below layer 0) ----
+        // Its result feeds nothing on the recurrence (the actor's input is detached: it only produces the pre-activation
+        // gradients for the weight-gradient GEMMs), so with d_actor_pre == NULL the caller runs it as ONE dense chain over
+        // all Hm x N rows from d_actor_out (bd_mlp_backward, tall form: 0.14 ms on the whole chip) instead of 45k of the
+        // 131k cycles of every step of every tile (s_memtime stamps).
+        if (a.d_actor_pre != nullptr) {
         {
             const Seg segs[2] = {{dAm, a.wt_a4m, d.Kb_a}, {dAr, a.wt_a4s, d.Kb_a}};
             tile_linear_pre<1, 2>(segs, nullptr, a.Hd, dpre_pre(a.sv_actor + 3 * act_stride, tn, a.Hd),
@@ -553,6 +558,7 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
                 lds_barrier();
                 float* tmp = src; src = dst; dst = tmp;
             }
+        }
         }
         BD_STAMP(26);
     }
@@ -626,7 +632,7 @@ int bd_imagine_backward(const bd_imagine_bwd_args* a, void* stream) {
     BD_REQUIRE(a->start_feat && a->feat && a->prior_std && a->action && a->eps_action && a->eps_prior && a->sv_actor &&
                    a->sv_act_stats && a->sv_x && a->sv_gates && a->sv_p && a->dfeat,
                "bd_imagine_backward: missing forward tensors");
-    BD_REQUIRE(a->d_actor_pre && a->d_actor_out, "bd_imagine_backward: missing outputs");
+    BD_REQUIRE(a->d_actor_out, "bd_imagine_backward: missing outputs");
     const ImgDims d(a->Be, a->S, a->A, a->Hd);
     // (the backward kernels have no element-wise Gaussian head: the split-K partials alone)
     const size_t lds = ((size_t)(6 * d.Kb_h + 3 * d.Kb_hd + 2 * d.Kb_s + 2 * d.Kb_a) * kFragFloats + 16 * a->S +

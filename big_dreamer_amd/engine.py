@@ -483,6 +483,7 @@ class DreamerEngine:
         Wa4 = self.W("actor", f"model.{2 * DENSE_LAYERS}.weight")
         add("actor", "a4m", Wa4[:A], tr=True)
         add("actor", "a4s", Wa4[A:], tr=True)
+        add("actor", "a4", Wa4, fwd=False, tr=True)     # (mean | raw) rows together: the hidden-layer backward as one chain
 
         self.pk: Dict[str, torch.Tensor] = {}
         self._pack_tables = {}
@@ -1470,10 +1471,20 @@ class DreamerEngine:
         c.dfeat = ptr(difeat)
         c.dentropy = -hp["entropy_weight"] * inv_mi if hp["entropy_weight"] != -1 else 0.0
         d_apre, d_aout = self.buf("d_actor_pre", DENSE_LAYERS, Mi, d.Hd), self.buf("d_actor_out", Mi, 2 * d.A)
-        c.d_actor_pre, c.d_actor_out = ptr(d_apre), ptr(d_aout)
+        # Gaussian latents: the actor's hidden layers leave the backward scan (their result feeds nothing on the
+        # recurrence: detached input) and run as one dense chain over all Hm x N rows from d_actor_out
+        actor_chain = (not d.categorical) and os.environ.get("BD_ACTOR_BWD_CHAIN", "1") == "1"
+        c.d_actor_pre, c.d_actor_out = (None if actor_chain else ptr(d_apre)), ptr(d_aout)
         c.ent_weight = ptr(wts)
         with self.span("imagine_bwd"):
             cabi.check((lib.bd_imagine_cat_backward if d.categorical else lib.bd_imagine_backward)(C.byref(c), st))
+        if actor_chain:
+            a_layers = [("a0h", None, d.Hd, F, cabi.ACT_ELU)] + [(f"a{l}", None, d.Hd, d.Hd, cabi.ACT_ELU)
+                                                                  for l in range(1, DENSE_LAYERS)] + \
+                       [("a4", None, 2 * d.A, d.Hd, cabi.ACT_NONE)]
+            with self.span("actor_hidden_bwd"):
+                self.mlp_backward(Mi, d_aout, 2 * d.A, a_layers, [sv_actor[l] for l in range(DENSE_LAYERS)] + [None],
+                                  [d_apre[l] for l in range(DENSE_LAYERS)] + [None])
         if self.pipeline:       # last reader of the world model in this step
             self._ev_bh_wm_free = torch.cuda.Event()
             self._ev_bh_wm_free.record(torch.cuda.current_stream())

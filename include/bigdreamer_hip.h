@@ -332,7 +332,9 @@ typedef struct {
     const float* dfeat;     /* [Hm x N x (Be+S)] from reward / value heads                           */
     float dentropy;         /* d loss / d entropy[t][n] (constant: -entropy_weight/(Hm*N))           */
     /* outputs for bd_wgrad */
-    float* d_actor_pre;     /* [4][Hm x N x Hd]                                                     */
+    float* d_actor_pre;     /* [4][Hm x N x Hd], or NULL: the actor's hidden layers are off the recurrence (detached
+                             * input); the caller then runs them as one chain over all rows from d_actor_out:
+                             * bd_mlp_backward(layers = actor, dout = d_actor_out, saved = sv_actor, dpre outputs)  */
     float* d_actor_out;     /* [Hm x N x 2A]                                                        */
     const float* ent_weight; /* optional [Hm x N] per-element factor on dentropy (use_discount=True: the cumulative
                               * discount weights of the actor objective, src/dreamer.py:346-351), or NULL          */
