@@ -907,6 +907,8 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_bwd_kernel(bd_imagine_ca
         lds_barrier();
         BD_KARGS_FRESH(ap);
         // ---- 6: actor MLP backward (input detached: no gradient below layer 0) ----
+        // (off the recurrence: with d_actor_pre == NULL the caller runs it as one dense chain over all rows, imagine.hip)
+        if (a.d_actor_pre != nullptr) {
         {
             const Seg segs[2] = {{dAm, a.wt_a4m, Kb_a}, {dAr, a.wt_a4s, Kb_a}};
             tile_linear_pre<1, 2>(segs, nullptr, a.Hd, dpre_pre(a.sv_actor + 3 * act_stride, tn, a.Hd),
@@ -923,6 +925,7 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_bwd_kernel(bd_imagine_ca
                 lds_barrier();
                 float* tmp = src; src = dst; dst = tmp;
             }
+        }
         }
     }
 #undef a
@@ -1013,7 +1016,7 @@ int bd_imagine_cat_backward(const bd_imagine_cat_bwd_args* a, void* stream) {
                "bd_imagine_cat_backward: missing weights");
     BD_REQUIRE(a->start_feat && a->feat && a->prior_logits && a->action && a->eps_action && a->sv_actor && a->sv_act_stats &&
                    a->sv_x && a->sv_gates && a->sv_p && a->dfeat, "bd_imagine_cat_backward: missing forward tensors");
-    BD_REQUIRE(a->d_actor_pre && a->d_actor_out, "bd_imagine_cat_backward: missing outputs");
+    BD_REQUIRE(a->d_actor_out, "bd_imagine_cat_backward: missing outputs");
     const int Kb_h = cdiv(a->Be, 16), Kb_a = cdiv(a->A, 16), Kb_hd = cdiv(a->Hd, 16);
     size_t uni = (size_t)2 * g.image_floats() + (size_t)(g.CW / 16) * kFragFloats;
     if ((size_t)kSplitScratchFloats > uni) uni = (size_t)kSplitScratchFloats;

@@ -1471,9 +1471,9 @@ class DreamerEngine:
         c.dfeat = ptr(difeat)
         c.dentropy = -hp["entropy_weight"] * inv_mi if hp["entropy_weight"] != -1 else 0.0
         d_apre, d_aout = self.buf("d_actor_pre", DENSE_LAYERS, Mi, d.Hd), self.buf("d_actor_out", Mi, 2 * d.A)
-        # Gaussian latents: the actor's hidden layers leave the backward scan (their result feeds nothing on the
-        # recurrence: detached input) and run as one dense chain over all Hm x N rows from d_actor_out
-        actor_chain = (not d.categorical) and os.environ.get("BD_ACTOR_BWD_CHAIN", "1") == "1"
+        # the actor's hidden layers leave the backward scan (their result feeds nothing on the recurrence: detached
+        # input) and run as one dense chain over all Hm x N rows from d_actor_out
+        actor_chain = os.environ.get("BD_ACTOR_BWD_CHAIN", "1") == "1"
         c.d_actor_pre, c.d_actor_out = (None if actor_chain else ptr(d_apre)), ptr(d_aout)
         c.ent_weight = ptr(wts)
         with self.span("imagine_bwd"):
