@@ -593,10 +593,12 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
                         a.action[(tn + grow) * A + col] = act;
                         mean_s[row * A + col] = mean;
                         std_s[row * A + col] = sd;
-                        if (a.sv_act_stats) {
+                        if (a.sv_act_stats) {      // slots 2, 3: mean and std for bd_actor_entropy, which replaces them
                             float* st = a.sv_act_stats + (tn + grow) * 4 * A + col;
                             st[0] = th;
                             st[A] = sigmoidf(pre);
+                            st[2 * A] = mean;
+                            st[3 * A] = sd;
                         }
                     }
                     af[frag_idx(row, col)] = act;
@@ -605,7 +607,9 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
         lds_barrier();
         BD_KARGS_FRESH(ap);
         // ---- entropy: n_samples draws per (row, action dim); thread = (row, sample lane) ----
-        {
+        // (off the recurrence when the actor statistics are saved: bd_actor_entropy after the scan, see imagine.hip)
+        const bool ent_inline = a.sv_act_stats == nullptr;
+        if (ent_inline) {
             const int row = tid & 15, sl = tid >> 4;
             const int grow = row0 + row;
             for (int j = 0; j < A; ++j) {
@@ -627,26 +631,18 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
                     p[0] = lp; p[1] = dm; p[2] = ds;
                 }
             }
-        }
-        lds_barrier();
-        for (int i = tid; i < 16 * A; i += blockDim.x) {
-            const int row = i / A, j = i - row * A, grow = row0 + row;
-            float lp = 0.f, dm = 0.f, ds = 0.f;
-            for (int w = 0; w < kWaves; ++w) {
-                const float* p = part + ((w * 16 + row) * A + j) * 3;
-                lp += p[0]; dm += p[1]; ds += p[2];
-            }
-            lp_rj[i] = lp;
-            if (grow < a.N && a.sv_act_stats) {
-                float* st = a.sv_act_stats + (tn + grow) * 4 * A + j;
-                st[2 * A] = -dm * inv_ns;
-                st[3 * A] = -ds * inv_ns;
+            lds_barrier();
+            for (int i = tid; i < 16 * A; i += blockDim.x) {
+                const int row = i / A, j = i - row * A;
+                float lp = 0.f;
+                for (int w = 0; w < kWaves; ++w) lp += part[((w * 16 + row) * A + j) * 3];
+                lp_rj[i] = lp;
             }
         }
         // W_es s as a gather (xs is free since actor layer 0)
         state_gather(g, a.w_embed_sT, a.Be, sidx_l, sw_l, nullptr, xs);
         lds_barrier();
-        if (tid < 16 && row0 + tid < a.N) {
+        if (ent_inline && tid < 16 && row0 + tid < a.N) {
             float s = 0.f;
             for (int j = 0; j < A; ++j) s += lp_rj[tid * A + j];
             a.entropy[tn + row0 + tid] = -s * inv_ns;
@@ -1005,6 +1001,8 @@ int bd_imagine_cat_forward(const bd_imagine_cat_fwd_args* a, void* stream) {
     if (lds > 64 * 1024 && allow_big_lds(imagine_cat_fwd_kernel)) return -1;
     hipLaunchKernelGGL(imagine_cat_fwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);
     BD_CHECK_LAUNCH("bd_imagine_cat_forward");
+    if (a->sv_act_stats != nullptr)     // the entropy estimate is off the recurrence (imagine.hip)
+        return bd_actor_entropy(a->eps_entropy, a->sv_act_stats, a->entropy, a->Hm, a->N, a->A, a->n_samples, stream);
     return 0;
 }
 
