@@ -408,7 +408,10 @@ __device__ __forceinline__ void wgrad_dense_body(const bd_wgrad_desc& d, float* 
         const bool more = st + 2 < nst;
         [[maybe_unused]] const int sb = (st == 10 || st == 11) ? (st - 10) * 8 : -1;   // diagnostic stamps (-DBD_STAMPS)
         BD_DSTAMP(sb, 0);
-        if (more) issue(wlds + ((st + 2) % kWRing) * kWStage, m_begin + (st + 2) * kWRows);
+        // The two waves of a SIMD (w, w + 4) issue the DMA of stage st+2 at different points of the stage: one before its
+        // MFMAs, the other after its second slice -- each wave's DMA instructions then go out while its SIMD-mate streams
+        // MFMAs, instead of both issuing first with the matrix pipe idle.
+        if (more && wave < 4) issue(wlds + ((st + 2) % kWRing) * kWStage, m_begin + (st + 2) * kWRows);
         BD_DSTAMP(sb, 1);
         const float* Pb = buf + lrow * kWLd + my_nb0 * 16 + lcol;
         const float* Ab = buf + kWRows * kWLd + lrow * kWLd + my_kb0 * 16 + lcol;
@@ -423,6 +426,7 @@ __device__ __forceinline__ void wgrad_dense_body(const bd_wgrad_desc& d, float* 
             for (int i = 0; i < WN; ++i)
 #pragma unroll
                 for (int j = 0; j < WK; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+            if (sl == 1 && more && wave >= 4) issue(wlds + ((st + 2) % kWRing) * kWStage, m_begin + (st + 2) * kWRows);
         }
         BD_DSTAMP(sb, 2);
         // stage st+1 must have landed; a full stage st+2 (4 DMA instructions of this wave) may stay in flight
