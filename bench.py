@@ -39,11 +39,18 @@ def algorithmic(d):
     actor = (d.Be + s_in) * d.Hd + 3 * d.Hd * d.Hd + d.Hd * 2 * d.A
     F = d.Be + s_in
     img_fwd = 2 * (actor + embed + gru + prior)                   # FLOP per imagined transition
-    img_bwd = 2 * (prior + gru + embed + (actor - F * d.Hd))      # layer-0 dgrad is not needed (detached input)
+    # backward: layer-0 dgrad of the actor is not needed (detached input).  With BD_ACTOR_BWD_CHAIN=1 (default,
+    # engine._behaviour_phase) the actor's hidden-layer dgrads (a4^T, a3^T, a2^T, a1^T) leave the scan and run as one
+    # dense chain over all Hm x N rows: they are credited to the `actor_hidden_bwd` span, not to the scan
+    actor_hidden = 3 * d.Hd * d.Hd + d.Hd * 2 * d.A
+    actor_chain = os.environ.get("BD_ACTOR_BWD_CHAIN", "1") == "1"
+    img_bwd = 2 * (prior + gru + embed + (0 if actor_chain else actor_hidden))
     obs_fwd = 2 * (embed + gru + d.Be * d.Hd + d.Hd * d.head_out)  # posterior hidden (belief half) + head
     rows_img = d.Hm * d.N
     flops = {"imagine_fwd": img_fwd * rows_img, "imagine_bwd": img_bwd * rows_img,
              "observe_fwd": obs_fwd * d.N, "observe_bwd": obs_fwd * d.N}
+    if actor_chain:
+        flops["actor_hidden_bwd"] = 2 * actor_hidden * rows_img
     # dense head chains over the imagined rows (F -> Hd x4 -> 1) and the weight-gradient GEMMs of the three passes:
     # spans of several launches, reported in kernel_tflops only (never the dominant kernel)
     head = 2 * (F * d.Hd + 3 * d.Hd * d.Hd + d.Hd)
@@ -64,17 +71,47 @@ def algorithmic(d):
     return flops, step_bytes
 
 
-def measured_traffic(kernel, kind=""):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary of the SAME workload
-    (profiles/*_traffic.json for configs[1], profiles/*_pixel_traffic.json for configs[2]: separate --pmc FETCH_SIZE /
-    WRITE_SIZE passes, FETCH_SIZE doubled for gfx950).  None if absent."""
+def _traffic_record(kernel, kind=""):
+    """(record, file name) of `kernel` in the newest committed rocprofv3 PMC summary of the SAME workload
+    (profiles/*_traffic.json for configs[1], *_pixel_traffic.json for configs[2], *_cat_traffic.json / *_catstate_traffic.json
+    for configs[4] on pixels / state observations), or None."""
     import glob
-    tagged = lambda f: next((k for k in ("pixel", "cat") if f"_{k}_traffic" in os.path.basename(f)), "")
+    tagged = lambda f: next((k for k in ("pixel", "catstate", "cat") if f"_{k}_traffic" in os.path.basename(f)), "")
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")) if tagged(f) == kind)
     if not files:
-        return None, None
+        return None
     t = json.load(open(files[-1])).get(kernel)
-    return (t["hbm_bytes_per_launch"], os.path.basename(files[-1])) if t else (None, None)
+    return (t, os.path.basename(files[-1])) if t else None
+
+
+def measured_traffic(kernel, kind=""):
+    """HBM bytes per launch of `kernel` from that record (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE
+    doubled for gfx950).  (None, None) if absent."""
+    rec = _traffic_record(kernel, kind)
+    return (rec[0]["hbm_bytes_per_launch"], rec[1]) if rec else (None, None)
+
+
+MFMA_F32_16X16X4_FLOP = 2048      # 16 x 16 x 4 MACs x 2 per v_mfma_f32_16x16x4_f32 (every kernel of the path issues this shape)
+
+
+def counter_checked_tflops(flops, kt, kind=""):
+    """kernel_tflops with a self-check: an entry whose ALGORITHMIC FLOPs per launch exceed what the kernel EXECUTES per
+    launch by the newest committed PMC record of the same workload (SQ_INSTS_VALU_MFMA_F32 x 2048,
+    profiles/*_traffic.json) is a wrong FLOP model, not a fast kernel: it is refused (listed under `refused`) rather
+    than printed.  Returns (tflops dict, refused dict)."""
+    ok, refused = {}, {}
+    for k in flops:
+        if k not in kt:
+            continue
+        rate = round(flops[k] / (kt[k][0] * 1e-3) / 1e12, 2)
+        rec = _traffic_record(k, kind)
+        if rec is not None and rec[0].get("mfma_f32_insts"):
+            executed = rec[0]["mfma_f32_insts"] * MFMA_F32_16X16X4_FLOP
+            if flops[k] > 1.02 * executed:
+                refused[k] = {"algorithmic_flop": flops[k], "executed_flop_by_counter": executed, "source": rec[1]}
+                continue
+        ok[k] = rate
+    return ok, refused
 
 
 def log(msg):
@@ -268,6 +305,9 @@ def main():
     ap.add_argument("--categorical", choices=["pixel", "state"], default=None,
                     help="BASELINE.json configs[4] per GPU: 32x32 Categorical latents (algorithm=dreamerV2), batch 100 = 800/8, "
                          "64x64 pixel observations with action dim 17 ('pixel') or state observations ('state')")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="self-launched --gpus N only: seconds after which the rank processes are terminated (a stuck "
+                         "rendezvous or collective must not hold the GPUs forever)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo: tests only)")
     ap.add_argument("--same-device", action="store_true",
                     help="tests only: every rank on cuda:0 (needs --backend gloo: RCCL refuses two ranks on one device)")
@@ -277,7 +317,8 @@ def main():
     if args.gpus > 1 and not launch.launched_by_torchrun():
         # plain `python bench.py --gpus N`: become the launcher -- N fresh rank processes of this script, one per GPU;
         # this parent never touches HIP.  Rank 0 prints the JSON line.
-        sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+        sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                    timeout=args.launch_timeout))
 
     if args.surface_only:       # child of the default run: the workload through Dreamer.train_step, nothing else in the process
         from big_dreamer_amd import synth
@@ -332,7 +373,9 @@ def main():
         scans = ("imagine_fwd", "imagine_bwd", "observe_fwd", "observe_bwd")
         dom = max((k for k in kt if k in flops and k in scans), key=lambda k: flops[k])
         ach = flops[dom] / (kt[dom][0] * 1e-3) / 1e12
-        traffic, traffic_src = measured_traffic(dom, "cat" if args.categorical else ("pixel" if args.pixel else ""))
+        kind = ({"pixel": "cat", "state": "catstate"}[args.categorical] if args.categorical else ("pixel" if args.pixel else ""))
+        traffic, traffic_src = measured_traffic(dom, kind)
+        ktf, ktf_refused = counter_checked_tflops(flops, kt, kind)
         out = {
             "metric": "latent transitions/sec (RSSM + imagination) at batch=50 chunk=50 H=15" if not args.categorical
             else "latent transitions/sec (RSSM + imagination) at batch=100/GPU chunk=50 H=15, Categorical latents",
@@ -365,10 +408,14 @@ def main():
             "hbm_roofline_whole_step": {"achieved": step_bytes / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBPS,
                                         "unit": "GB/s", "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS,
                                         "algorithmic_bytes_per_step": step_bytes},
-            "kernel_tflops": {k: round(flops[k] / (kt[k][0] * 1e-3) / 1e12, 2) for k in flops if k in kt},
+            "kernel_tflops": ktf,
             "kernel_ms": {k: round(v[0], 4) for k, v in kt.items()},
             "losses": {k: round(v, 5) for k, v in logs.items()},
         }
+        if ktf_refused:
+            out["kernel_tflops_refused"] = ktf_refused
+            log(f"kernel_tflops: refused {sorted(ktf_refused)} (algorithmic FLOPs above the MFMA counter of the PMC record)")
+        assert dom in ktf, f"the dominant kernel's FLOP model ({dom}) exceeds its MFMA counter: {ktf_refused.get(dom)}"
     del eng
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_secondary and not args.pixel and not args.categorical:

@@ -184,9 +184,6 @@ _SIGS = {
     "bd_actor_entropy": (I32, [P, P, P, I32, I32, I32, I32, P]),
     "bd_imagine_backward": (I32, [C.POINTER(ImagineBwdArgs), P]),
     "bd_lambda_return_forward": (I32, [P, P, I32, I32, F32, F32, P, P]),
-    "bd_dense_ws_supported": (I32, [I32, I32, I32]),
-    "bd_dense_ws": (I32, [P, I32, P, P, P, I32, I32, I32, I32, P, I32, P]),
-    "bd_mfma_probe": (I32, [I32, I32, P, P]),
     "bd_categorical_head_forward": (I32, [P, P, I32, I32, I32, P, P, P]),
     "bd_categorical_head_backward": (I32, [P, P, I32, I32, I32, P, P]),
     "bd_kl_categorical_forward": (I32, [P, P, I32, I32, I32, F32, I32, P, I32, P, P]),

@@ -525,10 +525,17 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
     float* lg = uni;                              // all S prior logits of the tile (swizzled image)
 
     load_tile_concat<1>(h_cur, Kb_h, row0, a.N, a.start_feat, F, a.Be, nullptr, 0, 0);
-    for (int i = threadIdx.x; i < 16 * g.D; i += blockDim.x) {
-        const int row = i / g.D;
-        sidx_l[i] = row < rows_valid ? (int)a.start_sidx[(size_t)row0 * g.D + i] : 0;
-        sw_l[i] = row < rows_valid ? 1.f : 0.f;
+    if (a.start_sidx) {
+        for (int i = threadIdx.x; i < 16 * g.D; i += blockDim.x) {
+            const int row = i / g.D;
+            sidx_l[i] = row < rows_valid ? (int)a.start_sidx[(size_t)row0 * g.D + i] : 0;
+            sw_l[i] = row < rows_valid ? 1.f : 0.f;
+        }
+    } else {
+        // no indices given (API callers: Dreamer.get_action / imagine_ahead on a dense state): every factor of the
+        // dense start state is all-zero (the collect loop's initial state, src/main.py:91-95: the actor and the embed
+        // layer then see zeros, as in the reference) or one-hot -- same rule as the observe scan's init_state
+        state_to_indices(g, a.start_feat + a.Be, (size_t)F, row0, a.N, sidx_l, sw_l);
     }
     for (int i = threadIdx.x; i < Kb_a * kFragFloats; i += blockDim.x) af[i] = 0.f;
     lds_barrier();
@@ -696,8 +703,11 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
         lds_barrier();
         cat_head_forward_full(gf, bufA, Kb_hd, a.w_p2, a.b_p2, a.q_prior + (tn + row0) * S, a.prior_logits + (tn + row0) * S,
                               rows_valid, lg, sidx_l);
-        for (int i = tid; i < 16 * g.D; i += blockDim.x)
-            if (i / g.D < rows_valid) a.sidx[(tn + row0) * g.D + i] = (unsigned char)sidx_l[i];
+        for (int i = tid; i < 16 * g.D; i += blockDim.x) {
+            const bool ok = i / g.D < rows_valid;
+            if (ok) a.sidx[(tn + row0) * g.D + i] = (unsigned char)sidx_l[i];
+            sw_l[i] = ok ? 1.f : 0.f;      // a sampled state is one-hot whatever the start state's weights were (same i as below)
+        }
         write_onehot(g, sidx_l, sw_l, nullptr, a.feat + (tn + row0) * F + a.Be, (size_t)F, rows_valid);
         lds_barrier();
         float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;

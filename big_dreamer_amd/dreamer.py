@@ -124,9 +124,14 @@ class Dreamer:
                 getattr(self, key).load_state_dict(d[key])
             if "model_optimizer" in d:
                 self.engine.load_optimizer_state_dict("model", d["model_optimizer"])
-            for key in ("actor", "critic", "critic_target"):
+            for key in ("actor", "critic", "critic_target") + (("discount_model",) if self.use_discount else ()):
                 if key in d:
                     getattr(self, key).load_state_dict(d[key])
+            if self.use_discount and "discount_model" not in d and "model_optimizer" in d and d["model_optimizer"]["state"]:
+                import warnings      # (a checkpoint in the reference's five-key layout: that is what the reference does too)
+                warnings.warn("use_discount=True: the checkpoint carries Adam moments for the discount head (it is part of "
+                              "the world-model optimiser, src/dreamer.py:167-169) but not its weights, which stay freshly "
+                              "initialised")
             for key, group in (("actor_optimizer", "actor"), ("value_optimizer", "critic")):
                 if key in d:
                     self.engine.load_optimizer_state_dict(group, d[key])
@@ -134,12 +139,14 @@ class Dreamer:
     def save(self, path: str) -> None:
         """Checkpoint in the layout ``Planet.load`` reads (src/planet.py:109-114: transition_model, observation_model,
         reward_model, encoder, model_optimizer -- the reference can resume from it), plus actor / critic /
-        critic_target and their optimisers (src/dreamer.py:56-67 names) so that this framework resumes exactly.
+        critic_target, the discount head when ``use_discount`` is set (its parameters are the tail of the world-model
+        optimiser, src/dreamer.py:167-169) and the actor / value optimisers (src/dreamer.py:56-67 names) so that this
+        framework resumes exactly.
         The reference declares ``save`` (src/base_agent.py:29-34) but never implements it (src/main.py:274 TODO)."""
         e = self.engine
         d = {key: {k: v.detach().cpu().clone().contiguous() for k, v in getattr(self, key).state_dict().items()}
              for key in ("transition_model", "observation_model", "reward_model", "encoder", "actor", "critic",
-                         "critic_target")}
+                         "critic_target") + (("discount_model",) if self.use_discount else ())}
         d["model_optimizer"] = e.optimizer_state_dict("model")
         d["actor_optimizer"] = e.optimizer_state_dict("actor")
         d["value_optimizer"] = e.optimizer_state_dict("critic")

@@ -93,7 +93,7 @@ class ParamGroup:
         return st.permute(0, 3, 1, 2) if perm else st
 
 
-def _adam_state_dict(g: ParamGroup, lr: float, hp: dict) -> dict:
+def _adam_state_dict(g: ParamGroup, lr: float, hp: dict, over: Optional[dict] = None) -> dict:
     """The group's optimiser state in torch.optim.Adam's state_dict layout (parameter index = reference parameter
     order, moments in the reference's logical shapes), so that the reference's ``model_optimizer.load_state_dict``
     accepts it (src/planet.py:114)."""
@@ -101,17 +101,26 @@ def _adam_state_dict(g: ParamGroup, lr: float, hp: dict) -> dict:
     for i, (mod, name, _shape) in enumerate(g.specs):
         state[i] = {"step": torch.tensor(float(g.step)), "exp_avg": g.logical(g.m, mod, name).detach().cpu().clone().contiguous(),
                     "exp_avg_sq": g.logical(g.v, mod, name).detach().cpu().clone().contiguous()}
-    group = {"lr": lr, "betas": (0.9, 0.999), "eps": hp["adam_epsilon"], "weight_decay": hp["weight_decay"], "amsgrad": False,
+    over = over or {}
+    group = {"lr": over.get("lr", lr), "betas": (0.9, 0.999), "eps": over.get("eps", hp["adam_epsilon"]),
+             "weight_decay": over.get("weight_decay", hp["weight_decay"]), "amsgrad": False,
              "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
              "params": list(range(len(g.specs)))}
     return {"state": state, "param_groups": [group]}
 
 
-def _load_adam_state_dict(g: ParamGroup, sd: dict) -> None:
+def _load_adam_state_dict(g: ParamGroup, sd: dict) -> Optional[dict]:
+    """Restore moments + step; returns the checkpoint's param_group hyper-parameters (lr, eps, weight_decay) -- torch's
+    ``Optimizer.load_state_dict`` adopts them (src/planet.py:114), so the caller does too."""
+    pg = (sd.get("param_groups") or [None])[0]
+    hyper = {k: float(pg[k]) for k in ("lr", "eps", "weight_decay") if pg and k in pg} or None
+    if pg and tuple(pg.get("betas", (0.9, 0.999))) != (0.9, 0.999):
+        raise NotImplementedError(f"Adam betas {pg['betas']} in the checkpoint: the kernels implement (0.9, 0.999), the "
+                                  "reference's only setting (src/dreamer.py:56-67)")
     st = sd["state"]
     if not st:                      # a freshly built optimiser: nothing to restore
         g.m.zero_(); g.v.zero_(); g.step = 0
-        return
+        return hyper
     assert len(st) == len(g.specs), f"optimizer state has {len(st)} parameters, this group {len(g.specs)}"
     steps = set()
     for i, (mod, name, shape) in enumerate(g.specs):
@@ -122,6 +131,7 @@ def _load_adam_state_dict(g: ParamGroup, sd: dict) -> None:
         steps.add(int(float(e["step"])))
     assert len(steps) == 1, f"per-parameter Adam step counts differ: {steps}"
     g.step = steps.pop()
+    return hyper
 
 
 class _LogRecord:
@@ -314,6 +324,7 @@ class DreamerEngine:
             self._main_stream = torch.cuda.Stream(self.dev)
             torch.cuda.set_stream(self._main_stream)
         self._pending_opt: List[tuple] = []
+        self._opt_over: Dict[str, dict] = {}
         self._log_ring: List[_LogRecord] = []
         self._log_i = 0
         self._cur_rec: Optional[_LogRecord] = None
@@ -395,12 +406,21 @@ class DreamerEngine:
         self.flush_optimizers()
         self.join()
         torch.cuda.current_stream().synchronize()
-        return _adam_state_dict(self.groups[group], self.hp[self._OPT[group]], self.hp)
+        return _adam_state_dict(self.groups[group], self.hp[self._OPT[group]], self.hp, self._opt_over.get(group))
 
     def load_optimizer_state_dict(self, group: str, sd: dict) -> None:
+        """Moments, step count AND the checkpoint's lr / eps / weight_decay (torch's Optimizer.load_state_dict adopts the
+        saved param_group, so a run resumed by the reference continues with the checkpoint's settings, src/planet.py:114)."""
         self.flush_optimizers()
         self.join()
-        _load_adam_state_dict(self.groups[group], sd)
+        hyper = _load_adam_state_dict(self.groups[group], sd)
+        if hyper:
+            mine = {"lr": self.hp[self._OPT[group]], "eps": self.hp["adam_epsilon"], "weight_decay": self.hp["weight_decay"]}
+            diff = {k: (mine[k], v) for k, v in hyper.items() if v != mine[k]}
+            if diff:
+                import warnings
+                warnings.warn(f"{group} optimiser: adopting the checkpoint's hyper-parameters (configured, checkpoint): {diff}")
+            self._opt_over[group] = hyper
 
     def state_dict(self, mod: str) -> Dict[str, torch.Tensor]:
         g = self.groups[self._mod_group[mod]]
@@ -575,9 +595,13 @@ class DreamerEngine:
         self._allreduce(g.grad, group)       # grads already carry 1/global-count: SUM over ranks = global-mean gradient
         g.step += 1
         hp = self.hp
+        ov = self._opt_over.get(group)          # hyper-parameters adopted from a checkpoint (load_optimizer_state_dict)
+        if ov:
+            lr = ov.get("lr", lr)
+        eps, wd = (ov or {}).get("eps", hp["adam_epsilon"]), (ov or {}).get("weight_decay", hp["weight_decay"])
         cabi.check(lib.bd_sumsq(ptr(g.grad), g.numel, ptr(self.scalars), slot, ptr(red_ws), cabi.stream()))
         cabi.check(lib.bd_adam_step(ptr(g.flat), ptr(g.grad), ptr(g.m), ptr(g.v), g.numel, lr, 0.9, 0.999,
-                                    hp["adam_epsilon"], hp["weight_decay"], g.step, hp["grad_clip_norm"],
+                                    eps, wd, g.step, hp["grad_clip_norm"],
                                     ptr(self.scalars), slot, cabi.stream()))
         self.pack(group)
         rec = rec if rec is not None else self._cur_rec
@@ -605,13 +629,23 @@ class DreamerEngine:
         stream, behind the kernels of this phase that wrote its slots."""
         rec.host[row, :N_SLOTS].copy_(self.scalars, non_blocking=True)
         if row == 0 and self._obs_ws is not None and self._obs_err_off is not None:
-            rec.host[row, N_SLOTS:].copy_(self._obs_ws[self._obs_err_off:self._obs_err_off + 1], non_blocking=True)
+            rec.host[row, N_SLOTS:].copy_(self._cluster_error_word(), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         rec.events[row] = ev
 
     def _resolve_record(self, rec: _LogRecord) -> Dict[str, float]:
-        self.flush_optimizers()            # data-parallel: the step's actor / critic updates may still be queued on the host
+        # The actor / critic updates of the LATEST step may still be held back on the host (deferred schedule).  Issuing
+        # them contains all-reduces: with several ranks a dict read -- which only one rank may make (rank 0 logging), or
+        # which a recycled record makes on the ranks that still hold its dict -- must never do that: the ranks' collectives
+        # would be issued in different orders on the shared communicator.  One rank: flush (no collective involved).
+        if any(p[6] is rec for p in self._pending_opt):
+            if self.world_size > 1:
+                raise RuntimeError("log dict of a train step whose actor / critic updates are still queued (data-parallel "
+                                   "deferred schedule): call train_step(), update_critic(), update_belief_and_act() or "
+                                   "flush_optimizers() on EVERY rank before reading it -- reading a log dict never issues "
+                                   "collectives")
+            self.flush_optimizers()
         for row in rec.need:
             assert rec.events[row] is not None, "log record read before its step was queued"
             rec.events[row].synchronize()
@@ -623,6 +657,19 @@ class DreamerEngine:
             s[slot] = h[2, slot]
         self._raise_on_cluster_error(int(h[0, N_SLOTS:].view(np.uint32)[0]))
         return self._logs_from(s, rec.counts)
+
+    def _cluster_error_word(self) -> torch.Tensor:
+        """The sticky error word of the cluster scans as one float32-typed element (bit pattern of the uint32 word).
+        Data-parallel: a time-out on ANY rank must stop EVERY rank at the same log read (a rank that raised alone would
+        leave the others waiting in their next all-reduce), so the ranks' "some member timed out" flags are summed on the
+        world-model communicator -- right behind the gradient all-reduce the model optimiser step has just issued, in
+        the same order on all ranks -- and the result is reported as forward+backward (bits 1|2)."""
+        w = self._obs_ws[self._obs_err_off:self._obs_err_off + 1]
+        if self.world_size <= 1:
+            return w
+        flag = (w.view(torch.int32) != 0).to(torch.float32)
+        self._allreduce(flag, "model")
+        return torch.where(flag > 0, torch.full_like(flag, 3).to(torch.int32), torch.zeros_like(flag).to(torch.int32)).view(torch.float32)
 
     def _raise_on_cluster_error(self, word: int) -> None:
         if word:
@@ -892,8 +939,15 @@ class DreamerEngine:
                 split: bool = False, start_sidx: Optional[torch.Tensor] = None):
         d, pk = self.d, self.pk
         if d.categorical:
-            if start_sidx is None:      # API callers hand dense one-hot states
-                start_sidx = start_feat[:, d.Be:].reshape(N, d.cat_D, d.cat_C).argmax(-1).to(torch.uint8).contiguous()
+            if start_sidx is None:
+                # API callers (Dreamer.get_action / imagine_ahead / update_belief_and_act) hand a DENSE state: the kernel
+                # takes, per factor, the all-zero case (the collect loop's initial state, src/main.py:91-95: the actor and
+                # the embed layer see zeros, as in the reference) or the one non-zero class.  Anything denser cannot be
+                # carried as class indices: refuse it rather than silently treat it as one-hot.
+                st = start_feat[:, d.Be:].reshape(N, d.cat_D, d.cat_C)
+                if int(((st != 0).sum(-1) > 1).any()):
+                    raise ValueError("Categorical latents: the start state must be all-zero or one-hot per factor "
+                                     f"({d.cat_D} x {d.cat_C}); got a factor with more than one non-zero class")
             return self._imagine_cat(start_feat, start_sidx, N, Hm, noise, save, tag, feat_tag)
         tm = lambda n: self.W("transition_model", n)
         ac = lambda n: self.W("actor", n)
@@ -1536,7 +1590,7 @@ class DreamerEngine:
         self.flush_optimizers()
         self.join()
         if self._obs_ws is not None and self._obs_err_off is not None:
-            both = torch.cat([self.scalars, self._obs_ws[self._obs_err_off:self._obs_err_off + 1]]).cpu().numpy()
+            both = torch.cat([self.scalars, self._cluster_error_word()]).cpu().numpy()
             self._raise_on_cluster_error(int(both[N_SLOTS:].view(np.uint32)[0]))
             s = both[:N_SLOTS].astype(np.float32)
         else:

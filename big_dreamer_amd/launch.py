@@ -36,40 +36,83 @@ def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = 
     return env
 
 
+def _stop(procs: Sequence[subprocess.Popen], grace: float = 15.0) -> None:
+    """Terminate, wait for, then kill exactly the processes we started (never a pattern)."""
+    live = [p for p in procs if p.poll() is None]
+    for p in live:
+        try:
+            p.terminate()
+        except OSError:
+            pass
+    t_end = time.monotonic() + grace
+    for p in live:
+        try:
+            p.wait(timeout=max(0.1, t_end - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            try:
+                p.kill()
+            except OSError:
+                pass
+            p.wait()
+
+
+class _Interrupted(Exception):
+    def __init__(self, signum: int):
+        self.signum = signum
+
+
 def spawn_ranks(argv: Sequence[str], world: int, timeout: Optional[float] = None,
                 extra_env: Optional[Dict[str, str]] = None) -> int:
     """Run `argv` (a full command line, e.g. [sys.executable, "bench.py", "--gpus", "8"]) as `world` ranks.
-    Returns 0 if every rank exited 0, else the first non-zero exit code (the remaining ranks are terminated)."""
+    Returns 0 if every rank exited 0, else the first non-zero exit code (the remaining ranks are terminated); 124 after
+    `timeout` seconds; 128 + signal when the launcher itself is told to stop.  However the call ends -- a failing rank,
+    the timeout, SIGTERM / SIGINT / SIGHUP delivered to the launcher (Ctrl-C, `timeout -k`, a harness limit), an
+    exception -- no rank process is left behind holding a GPU."""
+    import signal
     assert world >= 1
     port = free_port()
     procs: List[subprocess.Popen] = []
-    for r in range(world):
-        env = rank_env(r, world, port)
-        if extra_env:
-            env.update(extra_env)
-        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else sys.stderr))
-    t0 = time.monotonic()
+
+    def on_signal(signum, _frame):
+        raise _Interrupted(signum)
+
+    handled = (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)
+    old = {}
+    for sg in handled:
+        try:
+            old[sg] = signal.signal(sg, on_signal)
+        except ValueError:          # not the main thread: the caller's handlers stay, the finally below still cleans up
+            pass
     rc = 0
-    live = list(procs)
-    while live:
-        for p in list(live):
-            code = p.poll()
-            if code is None:
-                continue
-            live.remove(p)
-            if code != 0 and rc == 0:
-                rc = code
-        if rc != 0 or (timeout is not None and time.monotonic() - t0 > timeout):
-            if rc == 0:
+    try:
+        for r in range(world):
+            env = rank_env(r, world, port)
+            if extra_env:
+                env.update(extra_env)
+            procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+        t0 = time.monotonic()
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+            if rc != 0:
+                break
+            if timeout is not None and time.monotonic() - t0 > timeout:
+                print(f"[launch] ranks still running after {timeout:.0f} s: terminating them", file=sys.stderr, flush=True)
                 rc = 124
-            for p in live:                   # exact PIDs we started, never a pattern
-                p.terminate()
-            for p in live:
-                try:
-                    p.wait(timeout=15)
-                except subprocess.TimeoutExpired:
-                    p.kill()
-            break
-        if live:
-            time.sleep(0.05)
+                break
+            if live:
+                time.sleep(0.05)
+    except _Interrupted as e:
+        print(f"[launch] signal {e.signum}: terminating the rank processes", file=sys.stderr, flush=True)
+        rc = 128 + e.signum
+    finally:
+        _stop(procs)
+        for sg, h in old.items():
+            signal.signal(sg, h)
     return rc

@@ -79,6 +79,9 @@ SMALL = Dims(B=7, L=9, H=6, Be=48, S=10, Hd=36, E=72, A=3, O=4, n_entropy=100)
 # Categorical latents (algorithm=dreamerV2 latent_distribution=Categorical): ragged factors, then the reference's 32 x 32
 CAT_TINY = Dims(B=3, L=5, H=4, Be=24, S=15, Hd=20, E=40, A=2, O=5, cat_D=3, cat_C=5)
 CAT_32 = Dims(B=18, L=6, H=5, Be=64, S=1024, Hd=48, E=96, A=3, O=6, cat_D=32, cat_C=32)       # 32 x 32 latents, two row tiles
+# BASELINE configs[4] as stated -- pixel observations AND Categorical latents (decoder reads [h; one-hot s], K = Be + D*C)
+CAT_PIXEL_TINY = Dims(B=2, L=4, H=3, Be=24, S=15, Hd=20, E=1024, A=2, O=12288, pixel=True, cat_D=3, cat_C=5)
+CAT_PIXEL_32 = Dims(B=3, L=3, H=3, Be=40, S=1024, Hd=32, E=1024, A=17, O=12288, pixel=True, cat_D=32, cat_C=32)   # 32 x 32, A = 17
 CONFIG5 = Dims(B=100, A=17, O=12288, pixel=True, S=1024, cat_D=32, cat_C=32)   # BASELINE configs[4] per GPU: batch 800 / 8
 CONFIG5_STATE = Dims(B=100, S=1024, cat_D=32, cat_C=32)                         # same latents on state observations
 

@@ -350,19 +350,6 @@ int bd_lambda_return_forward(const float* reward, const float* value, int Hm, in
 int bd_lambda_return_backward(const float* dreturns, float dret_const, int Hm, int N, float discount,
                               float lambda_, float* dreward, float* dvalue, void* stream);
 
-/* ---- weight-stationary dense layer for tall inputs (csrc/dense_ws.hip): one layer of a DenseModel
- * (src/models.py:365-408) over M >> N rows with the weights resident in registers for the whole launch.
- * Forward (saved == NULL): out[M x N] = act(in[M x K] W^T + bias), w_packed = packed (N, K).
- * Backward dgrad (saved != NULL): out = (in W^T) * ELU'(saved[M x N]) -- with in = the gradient w.r.t. a layer's
- * pre-activation and w_packed its packed TRANSPOSE, out is the gradient w.r.t. the previous layer's pre-activation.
- * bd_dense_ws_supported: shapes this kernel takes (today: 193 <= K <= 208, K % 4 == 0, N <= 256, M >= 16). */
-int bd_dense_ws_supported(int M, int N, int K);
-int bd_dense_ws(const float* in, int ldi, const float* w_packed, const float* bias, const float* saved, int M, int N, int K,
-                int act, float* out, int ldo, void* stream);
-/* Diagnostic: register-only v_mfma_f32_16x16x4_f32 loop (16 waves per workgroup, 4 independent chains per wave) to measure
- * the fp32 MFMA rate this part sustains; flops = blocks * 16 * iters * 32 * 2048. */
-int bd_mfma_probe(int blocks, int iters, float* out, void* stream);
-
 /* ---- Categorical latents: CategoricalBeliefModel tail (src/models.py:108-117) and the Categorical branch of
  * Dreamer._kl_loss (src/dreamer.py:102-106,131-144).  logits / state / probs are [rows x D*C], D groups of C classes.
  * Forward: probs = softmax(logits) per group; state = one_hot(argmax(probs / q_noise)) with q_noise ~ Exp(1), which is
@@ -451,7 +438,9 @@ typedef struct {
     const float* w_a[3]; const float* b_a[4];
     const float* w_a4m; const float* w_a4s; const float* b_a4;
     const float* start_feat;                                   /* [N x (Be+S)] posterior features (one-hot s)  */
-    const unsigned char* start_sidx;                           /* [N x D]                                     */
+    const unsigned char* start_sidx;                           /* [N x D] class indices of start_feat's one-hot state, or NULL: every
+                                                                  factor of start_feat[:, Be:] is then all-zero (fed as zeros, like
+                                                                  the reference does with its initial state) or (scaled) one-hot   */
     const float* eps_action; const float* eps_entropy;         /* as bd_imagine_fwd_args                      */
     const float* q_prior;                                      /* [Hm x N x S] Exp(1) draws                   */
     float act_raw_init_std, act_min_std, act_mean_scale;

@@ -277,7 +277,7 @@ def run_config_categorical(dreamer_mod, name: str, d: synth.Dims, seed: int, **o
     """latent_distribution="Categorical": the reference's own Dreamer code (TransitionModel.forward, _kl_loss Categorical
     branch, imagine_ahead, train_step x2) under CategoricalShims.  The tiny cases are stored in full, the 32 x 32 ones as
     sums + strided samples (`store`)."""
-    full = d.S <= 64
+    full = d.S <= 64 and not d.pixel
     assert d.categorical
     out = {}
     P = synth.make_params(d, seed)
@@ -361,6 +361,10 @@ CATEGORICAL_RUNS = {        # name -> (Dims, seed, overrides); mirrored by tests
     "cat_tiny_klsum": (synth.CAT_TINY, 52, dict(kl_balance=-1, free_nats=0.01)),
     "cat_32": (synth.CAT_32, 53, dict(free_nats=0.0)),                     # the reference's 32 x 32 latents, batch 18
     "cat_32_v2": (synth.CAT_32, 54, dict()),                               # default free_nats=3 (clamp saturated)
+    # BASELINE configs[4] as stated: 64x64 pixel observations + Categorical latents (src/models.py:319-362 with
+    # state_size = D*C, src/planet.py:56-57), ragged 3 x 5 factors and the reference's 32 x 32 with A = 17
+    "cat_pixel_tiny": (synth.CAT_PIXEL_TINY, 55, dict(free_nats=0.0)),
+    "cat_pixel_32": (synth.CAT_PIXEL_32, 56, dict()),
 }
 
 
@@ -620,6 +624,10 @@ if __name__ == "__main__":
         torch.set_num_threads(8)
         dm, mm = _import_reference()
         for what in sys.argv[sys.argv.index("--only") + 1:]:
+            if what in CATEGORICAL_RUNS:
+                dd, sd_, ov = CATEGORICAL_RUNS[what]
+                run_config_categorical(dm, what, dd, sd_, **ov)
+                continue
             if what == "categorical_scan":
                 for name, (dd, sd_, ov) in CATEGORICAL_RUNS.items():
                     run_config_categorical(dm, name, dd, sd_, **ov)

@@ -29,6 +29,9 @@ CAT_CASES = {
     "cat_tiny_klsum": (synth.CAT_TINY, 52, dict(kl_balance=-1, free_nats=0.01), True),
     "cat_32": (synth.CAT_32, 53, dict(free_nats=0.0), False),
     "cat_32_v2": (synth.CAT_32, 54, dict(), False),
+    # BASELINE configs[4] as stated: pixel observations + Categorical latents
+    "cat_pixel_tiny": (synth.CAT_PIXEL_TINY, 55, dict(free_nats=0.0), False),
+    "cat_pixel_32": (synth.CAT_PIXEL_32, 56, dict(), False),
 }
 
 

@@ -55,7 +55,10 @@ def test_categorical_forward_pieces(name):
         ret = O.lambda_return(r, v, v[-1], od.hp["discount"], od.hp["disclam"])
     db, dn = _dev(batch), _dev(noise)
     T, B, N, Hm, F = d.T, d.B, d.N, d.Hm, d.Be + d.S
-    emb, pre = eng.encode(db["observations"][1:].reshape(N, d.O), N)
+    if d.pixel:     # configs[4] as stated: 64x64 pixel observations + Categorical latents
+        emb, pre = eng.encode_pixels(db["observations"][1:].reshape(N, 3, 64, 64))
+    else:
+        emb, pre = eng.encode(db["observations"][1:].reshape(N, d.O), N)
     feat, ql, _ = eng.observe(db["actions"][:-1], db["nonterminals"][:-1], pre, dn["obs_post"],
                               torch.zeros(B, d.Be, device="cuda"), torch.zeros(B, d.S, device="cuda"), T, B)
     pst, pl, _ = eng.prior_head(feat, N, dn["obs_prior"].reshape(N, d.S))
@@ -84,7 +87,8 @@ def test_categorical_forward_pieces(name):
         assert np.array_equal(fi[..., d.Be:], is_.numpy()), "imagined one-hot samples differ"
         _rel("imged_prior_logits", c(eng._buf["iprior_logits"]), il.reshape(Hm * N, -1), 5e-5, 5e-5, rep)
         _rel("action_entropy", c(e_ent).reshape(Hm, N), ent, 2e-2, 1e-3, rep)
-        assert abs(float(c(e_ent).mean()) - float(ent.mean())) < 2e-4
+        # mean: tight; with a dozen rows ONE ill-conditioned row at its own tolerance (2e-2) may move it by 2e-2 / rows
+        assert abs(float(c(e_ent).mean()) - float(ent.mean())) < max(2e-4, 2e-2 / (Hm * N))
         _rel("imged_reward", c(r_out).reshape(Hm, N, 1), r, 5e-5, 5e-5, rep)
         _rel("value_pred", c(v_out).reshape(Hm, N, 1), v, 5e-5, 5e-5, rep)
         _rel("returns", c(returns).reshape(Hm, N, 1), ret, 2e-4, 5e-5, rep)
@@ -201,6 +205,20 @@ def test_categorical_surface_matches_oracle():
     assert_close("imagine beliefs", ib.cpu().numpy(), wb.numpy(), 5e-5, 5e-5)
     assert np.array_equal(is_.cpu().numpy(), ws.numpy())
     assert_close("entropy", ent.cpu().numpy(), went.numpy(), 2e-2, 1e-3)
+    # an all-zero start state through the public surface (the collect loop's initial state, src/main.py:91-95): the actor
+    # and the embed layer must see zeros, as in the reference -- not "class 0 of every factor" 
+    nz0 = {"action": cu(noise["action"][:, :d.B].copy()), "entropy": cu(noise["entropy"][:, :, :d.B].copy()),
+           "img_prior": cu(noise["img_prior"][:, :d.B].copy())}
+    zb, zs, (zl,), zent = agent.imagine_ahead(torch.zeros(1, d.B, d.S).cuda(), out[0][:1].contiguous(), _noise=nz0)
+    wzb, wzs, (wzl,), wzent = O.imagine_ahead(tP, torch.zeros(1, d.B, d.S), want[0][:1], d.H,
+                                              torch.tensor(noise["action"][:, :d.B].copy()),
+                                              torch.tensor(noise["entropy"][:, :, :d.B].copy()),
+                                              torch.tensor(noise["img_prior"][:, :d.B].copy()), cat)
+    assert_close("zero-start beliefs", zb.cpu().numpy(), wzb.numpy(), 5e-5, 5e-5)
+    assert np.array_equal(zs.cpu().numpy(), wzs.numpy()), "zero-start sampled states"
+    assert_close("zero-start entropy", zent.cpu().numpy(), wzent.numpy(), 2e-2, 1e-3)
+    with pytest.raises(ValueError, match="one-hot per factor"):
+        agent.imagine_ahead(torch.full((1, d.B, d.S), 0.5).cuda(), out[0][:1].contiguous(), _noise=nz0)
     # one collect-loop decision from the all-zero start state (src/main.py:91-95), then one from the sampled state
     belief, state = torch.zeros(1, d.Be).cuda(), torch.zeros(1, agent.state_size).cuda()
     action = torch.zeros(1, d.A).cuda()
@@ -220,13 +238,16 @@ def test_categorical_surface_matches_oracle():
     assert all(np.isfinite(float(v)) for v in logs.values())
 
 
-def test_categorical_full_size_step_vs_oracle():
-    """BASELINE configs[4] per GPU at full size on state observations: 32 x 32 latents, batch 100 (= 800 / 8), chunk 50,
-    H 15, belief / hidden 200, embedding 1024 -- one whole train step against the oracle (no reference run at this size:
-    losses, gradient norms, every weight after Adam)."""
+@pytest.mark.parametrize("which", ["state", "pixel"])
+def test_categorical_full_size_step_vs_oracle(which):
+    """BASELINE configs[4] per GPU at full size: 32 x 32 latents, batch 100 (= 800 / 8), chunk 50, H 15, belief / hidden
+    200, embedding 1024 -- "state": on state observations (A = 1); "pixel": AS STATED, 64x64 pixel observations, A = 17
+    (the decoder reads [h; one-hot s], K = 1224; src/models.py:319-362, src/planet.py:56-57).  One whole train step
+    against the oracle (no reference run at this size; the path is pinned at small sizes by tests/golden/cat_*.npz):
+    losses, gradient norms, the clipped gradient of EVERY parameter tensor, every weight after Adam."""
     from big_dreamer_amd.engine import DreamerEngine
     from oracle import dreamer_oracle as O
-    d = synth.CONFIG5_STATE
+    d = synth.CONFIG5 if which == "pixel" else synth.CONFIG5_STATE
     P, batch, nz = synth.make_params(d, 71), synth.make_batch(d, 71), synth.make_noise(d, 71)
     torch.set_num_threads(16)
     od = O.OracleDreamer(P, dict(planning_horizon=d.H, categorical=(d.cat_D, d.cat_C), free_nats=0.0))
@@ -242,8 +263,23 @@ def test_categorical_full_size_step_vs_oracle():
         gn = od.last["grad_norms"]
         _rel("grad_norms", [logs["grad_norm_model"], logs["grad_norm_actor"], logs["grad_norm_critic"]],
              [gn["model"], gn["actor"], gn["critic"]], 1e-6, 2e-3, rep)
+        # per-tensor clipped gradients: after ONE Adam step a weight moves by ~lr * sign(g), so the weights alone do
+        # not check gradient magnitudes.  A handful of the 2.3 M sampled factors are near-ties that resolve differently
+        # between fp32 summation orders (the small cases compare samples exactly): tolerance relative to the tensor's
+        # own scale, as in the small cases.
+        coef = {k: min(1.0, od.hp["grad_clip_norm"] / (gn[k] + 1e-6)) for k in gn}
+        groups = {"model": (O.MODEL_MODULES, od.last["model_grads"]), "actor": (("actor",), od.last["actor_grads"]),
+                  "critic": (("critic",), od.last["critic_grads"])}
+        for grp, (mods, grads) in groups.items():
+            i = 0
+            for mod in mods:
+                for k in od.P[mod]:
+                    want = grads[i].numpy() * coef[grp]
+                    scale = float(np.abs(want).max()) + 1e-12
+                    _rel(f"grad.{mod}.{k}", eng.G(mod, k).detach().cpu().numpy(), want, 2e-3 * scale + 1e-9, 2e-3, rep)
+                    i += 1
         for mod in list(O.MODEL_MODULES) + ["actor", "critic"]:
             for k, p in od.P[mod].items():
                 _rel(f"param.{mod}.{k}", eng.W(mod, k).cpu().numpy(), p.detach().numpy(), 2e-5, 1e-5, rep)
     finally:
-        print("\n".join(rep[-80:]))
+        print("\n".join(rep[-160:]))

@@ -139,29 +139,3 @@ def test_gathered_wgrad_matches_conv_weight_gradients(Cin, Cout, k, size):
     gyts = conv.to_nhwc(gyt)
     conv.run_wgrad([conv.wgrad_desc(xts, Cout, gyts, imgs, OH, OH, HT, HT, Cin, k, dWt, None)])
     _close(dWt.permute(0, 3, 1, 2), gwt_ref, 1e-4)
-
-
-def test_weight_stationary_dense_layer_matches_torch():
-    """bd_dense_ws (csrc/dense_ws.hip; experimental, not on the product path -- DESIGN.md section 7): forward
-    out = ELU(x W^T + b) and the dgrad form out = (g W) * ELU'(saved) at a ragged row count, against torch."""
-    from big_dreamer_amd import _cabi as cabi
-    from big_dreamer_amd.categorical import _pack
-    torch.manual_seed(3)
-    M, K, N = 16 * 300 + 5, 200, 200
-    assert cabi.lib.bd_dense_ws_supported(M, N, K) == 1 and cabi.lib.bd_dense_ws_supported(M, N, 230) == 0
-    x = torch.randn(M, K, device="cuda")
-    W = torch.randn(N, K, device="cuda") / K ** 0.5
-    b = 0.1 * torch.randn(N, device="cuda")
-    out = torch.full((M, N), float("nan"), device="cuda")
-    cabi.check(cabi.lib.bd_dense_ws(x.data_ptr(), K, _pack(W, False).data_ptr(), b.data_ptr(), None, M, N, K, cabi.ACT_ELU,
-                                    out.data_ptr(), N, cabi.stream()))
-    ref = torch.nn.functional.elu(x @ W.t() + b)
-    assert torch.allclose(out, ref, atol=2e-5, rtol=2e-5), float((out - ref).abs().max())
-    g = torch.randn(M, N, device="cuda")
-    saved = torch.nn.functional.elu(torch.randn(M, K, device="cuda"))
-    dout = torch.full((M, K), float("nan"), device="cuda")
-    cabi.check(cabi.lib.bd_dense_ws(g.data_ptr(), N, _pack(W, True).data_ptr(), None, saved.data_ptr(), M, K, N, 0,
-                                    dout.data_ptr(), K, cabi.stream()))
-    refb = (g @ W) * torch.where(saved > 0, torch.ones_like(saved), saved + 1)
-    assert torch.allclose(dout, refb, atol=5e-5, rtol=5e-5), float((dout - refb).abs().max())
-    assert cabi.lib.bd_dense_ws(x.data_ptr(), K, None, None, None, M, N, K, 0, out.data_ptr(), N, cabi.stream()) != 0

@@ -38,3 +38,49 @@ def test_parent_of_a_multi_gpu_bench_never_initialises_hip():
     if not torch.cuda.is_available():
         assert out.returncode != 0 and out.stdout.strip() == ""
         assert "Traceback" in out.stderr          # from a rank, relayed
+
+
+def _pids_alive(pids):
+    alive = []
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            # a zombie still answers kill(0): read its state
+            with open(f"/proc/{pid}/stat") as f:
+                if f.read().split(")")[-1].split()[0] != "Z":
+                    alive.append(pid)
+        except (OSError, IOError):
+            pass
+    return alive
+
+
+def test_a_terminated_launcher_takes_its_ranks_down():
+    """SIGTERM to the launcher (a harness limit, `timeout -k`, Ctrl-C) must not orphan rank processes that hold GPUs:
+    the parent terminates exactly the Popen objects it started and exits 128 + signal."""
+    import signal
+    worker = ("import os, sys, time; print('PID', os.getpid(), flush=True); time.sleep(120)")
+    driver = ("import sys; sys.path.insert(0, %r); from big_dreamer_amd import launch; "
+              "sys.exit(launch.spawn_ranks([sys.executable, '-c', %r], 2, timeout=300))" % (ROOT, worker))
+    p = subprocess.Popen([sys.executable, "-c", driver], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+    pids = []
+    line = p.stdout.readline()                    # rank 0's stdout is passed through
+    assert line.startswith("PID"), line
+    pids.append(int(line.split()[1]))
+    time.sleep(1.0)                               # rank 1 has started by now as well (its PID goes to stderr)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    pids += [int(l.split()[1]) for l in err.splitlines() if l.startswith("PID")]
+    assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err[-2000:])
+    assert len(pids) == 2, (pids, err[-2000:])
+    time.sleep(0.2)
+    assert _pids_alive(pids) == [], "rank processes survived their launcher"
+
+
+def test_launch_timeout_terminates_hung_ranks():
+    worker = "import time; time.sleep(120)"
+    driver = ("import sys; sys.path.insert(0, %r); from big_dreamer_amd import launch; "
+              "sys.exit(launch.spawn_ranks([sys.executable, '-c', %r], 2, timeout=2))" % (ROOT, worker))
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-c", driver], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == 124 and time.time() - t0 < 60
+    assert "terminating them" in out.stderr

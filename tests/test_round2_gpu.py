@@ -149,18 +149,20 @@ def test_update_belief_and_act_matches_the_reference(case):
         assert_close(f"{case}.env_action{i}", env.got[-1], g[f"{case}.env_action{i}"], 2e-5, 2e-5)
 
 
-def test_checkpoint_roundtrip_restores_optimiser_state(tmp_path):
+@pytest.mark.parametrize("discount", [False, True])
+def test_checkpoint_roundtrip_restores_optimiser_state(tmp_path, discount):
     """save() -> load(): weights, Adam moments and step counts of all three optimisers; the resumed agent's next
-    train step is bit-identical to the original's."""
+    train step is bit-identical to the original's.  discount: use_discount=True -- the discount head is the tail of the
+    world-model optimiser (src/dreamer.py:167-169), so its weights must travel with the moments."""
     from big_dreamer_amd.config import load_config
     from big_dreamer_amd.dreamer import Dreamer
-    d = synth.SMALL
+    d = synth.TINY_DISCOUNT if discount else synth.SMALL
 
     class Env:
         action_size, observation_size = d.A, d.O
 
     ov = [f"belief_size={d.Be}", f"state_size={d.S}", f"hidden_size={d.Hd}", f"embedding_size={d.E}", f"batch_size={d.B}",
-          f"seq_len={d.L}", f"planning_horizon={d.H}", "experience_size=100"]
+          f"seq_len={d.L}", f"planning_horizon={d.H}", "experience_size=100"] + (["use_discount=true"] if discount else [])
     torch.manual_seed(5)
     a = Dreamer(load_config(ov), Env())
     batches = [_dev(synth.make_batch(d, 20 + i)) for i in range(4)]
@@ -182,11 +184,21 @@ def test_checkpoint_roundtrip_restores_optimiser_state(tmp_path):
         assert gb.step == ga.step == 3
         assert torch.equal(ga.flat, gb.flat) and torch.equal(ga.m, gb.m) and torch.equal(ga.v, gb.v)
     assert torch.equal(a.engine.groups["critic_target"].flat, b.engine.groups["critic_target"].flat)
+    if discount:
+        assert "discount_model" in ck and any(m == "discount_model" for m, _, _ in a.engine.groups["model"].specs)
     la = a.engine.train_step(batches[3], noises[3])
     lb = b.engine.train_step(batches[3], noises[3])
     assert la == lb
     for grp in ("model", "actor", "critic"):
         assert torch.equal(a.engine.groups[grp].flat, b.engine.groups[grp].flat)
+    if not discount:
+        # torch's Optimizer.load_state_dict adopts the checkpoint's lr / eps / weight_decay (src/planet.py:114): so does
+        # the engine -- an agent configured with another learning rate continues with the checkpoint's
+        with pytest.warns(UserWarning, match="adopting the checkpoint's hyper-parameters"):
+            c = Dreamer(load_config(ov + [f"models={path}", "model_learning_rate=0.5"]), Env())
+        assert c.engine._opt_over["model"]["lr"] == a.engine.hp["model_learning_rate"]
+        lc = c.engine.train_step(batches[3], noises[3])
+        assert lc == la and torch.equal(c.engine.groups["model"].flat, a.engine.groups["model"].flat)
 
 
 def test_non_contiguous_operands_are_rejected():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Weight-stationary dense layer (csrc/dense_ws.hip) against torch and against the chain kernel (bd_mlp_forward):
+"""Weight-stationary dense layer (tools/probes/dense_ws.hip) against torch and against the chain kernel (bd_mlp_forward):
 correctness of the forward and dgrad forms, then time per 200x200 layer at the imagination's 34 300 rows."""
 import ctypes as C
 import os
@@ -13,11 +13,13 @@ from big_dreamer_amd import _cabi as cabi  # noqa: E402
 from big_dreamer_amd.categorical import _pack  # noqa: E402
 
 lib = cabi.lib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes"))
+import probes  # noqa: E402  (tools/probes/libbd_probes.so: `make -C tools/probes`)
 
 
 def ws(x, pk, bias, saved, N, act, out):
     M, K = x.shape
-    cabi.check(lib.bd_dense_ws(x.data_ptr(), K, pk.data_ptr(), bias.data_ptr() if bias is not None else None,
+    probes.check(probes.lib.bd_dense_ws(x.data_ptr(), K, pk.data_ptr(), bias.data_ptr() if bias is not None else None,
                                saved.data_ptr() if saved is not None else None, M, N, K, act, out.data_ptr(), N, cabi.stream()))
 
 
@@ -88,7 +90,7 @@ def main():
 def mfma_peak():
     out = torch.zeros(4, device="cuda")
     for blocks, iters in ((256, 20000), (256, 100000), (512, 50000)):
-        f = lambda: cabi.check(lib.bd_mfma_probe(blocks, iters, out.data_ptr(), cabi.stream()))
+        f = lambda: probes.check(probes.lib.bd_mfma_probe(blocks, iters, out.data_ptr(), cabi.stream()))
         us = timed(f, 5)
         flops = blocks * 16 * iters * 32 * 2048.0
         print(f"MFMA-only loop, {blocks} workgroups x 16 waves, {iters} iterations: {us / 1e3:.2f} ms -> {flops / us / 1e6:.1f} TFLOP/s "

@@ -11,9 +11,15 @@
 // no weight traffic; activations make one HBM round trip per layer.
 #include "bd_device.h"
 #include "bd_host.h"
+#include "bd_probes.h"
 #include <stdlib.h>
 
 namespace bd {
+
+char* err_buf() {
+    static thread_local char buf[512];
+    return buf;
+}
 
 constexpr int kWsWaves = 16;                 // up to 16 output column blocks (N <= 256)
 constexpr int kWsThreads = kWsWaves * 64;
@@ -238,3 +244,5 @@ int bd_mfma_probe(int blocks, int iters, float* out, void* stream) {
 }
 
 }  // extern "C"
+
+extern "C" const char* bd_probe_last_error(void) { return bd::err_buf(); }
