@@ -177,6 +177,10 @@ _SIGS = {
     "bd_gauss_head_backward": (I32, [P, P, P, P, P, I32, I32, P, P]),
     "bd_observe_cat_forward": (I32, [C.POINTER(ObserveCatFwdArgs), P]),
     "bd_observe_cat_backward": (I32, [C.POINTER(ObserveCatBwdArgs), P]),
+    "bd_observe_cat_cluster_size": (I32, [I32, I32, I32, I32, I32]),
+    "bd_observe_cat_cluster_ws_floats": (C.c_size_t, [I32, I32, I32, I32, I32]),
+    "bd_observe_cat_forward_cluster": (I32, [C.POINTER(ObserveCatFwdArgs), I32, P, C.c_size_t, P]),
+    "bd_observe_cat_backward_cluster": (I32, [C.POINTER(ObserveCatBwdArgs), I32, P, C.c_size_t, P]),
     "bd_imagine_cat_forward": (I32, [C.POINTER(ImagineCatFwdArgs), P]),
     "bd_imagine_cat_backward": (I32, [C.POINTER(ImagineCatBwdArgs), P]),
     "bd_imagine_forward": (I32, [C.POINTER(ImagineFwdArgs), P]),

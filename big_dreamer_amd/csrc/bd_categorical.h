@@ -407,4 +407,87 @@ __device__ __forceinline__ void cat_head_forward(const CatGeo& g, const float* _
     }
 }
 
+// ---- the one-hot state as class indices (shared by scan_cat.hip and observe_cat_cluster.hip) ----------------------------
+// gather-sum of the state columns of a first layer: out[row][col] = scale[row] * sum_f w[row][f] * WT[(f*C + idx[row][f]) * N + col]
+__device__ __forceinline__ void state_gather(const CatGeo& g, const float* __restrict__ WT, int N, const int* __restrict__ sidx_l,
+                                             const float* __restrict__ sw_l, const float* __restrict__ scale_l,
+                                             float* __restrict__ out) {
+    if ((N & 3) == 0) {     // 16-byte loads, eight rows of the gather in flight per thread
+        const int N4 = N >> 2;
+        for (int i = bd_tid(); i < 16 * N4; i += blockDim.x) {
+            const int row = i / N4, c4 = i - row * N4;
+            const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(WT) + c4;
+            floatx4 s = floatx4{0.f, 0.f, 0.f, 0.f};
+            int f = 0;
+            for (; f + 8 <= g.D; f += 8) {
+                floatx4 t[8];
+                float w[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    w[j] = sw_l[row * g.D + f + j];
+                    t[j] = W4[(size_t)((f + j) * g.C + sidx_l[row * g.D + f + j]) * N4];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += w[j] * t[j];
+            }
+            for (; f < g.D; ++f) s += sw_l[row * g.D + f] * W4[(size_t)(f * g.C + sidx_l[row * g.D + f]) * N4];
+            if (scale_l) s *= scale_l[row];
+            reinterpret_cast<floatx4*>(out)[i] = s;
+        }
+        return;
+    }
+    for (int i = bd_tid(); i < 16 * N; i += blockDim.x) {
+        const int row = i / N, col = i - row * N;
+        float s = 0.f;
+        for (int f = 0; f < g.D; ++f) {
+            const float w = sw_l[row * g.D + f];
+            const int k = f * g.C + sidx_l[row * g.D + f];
+            s += w * WT[(size_t)k * N + col];
+        }
+        out[i] = scale_l ? s * scale_l[row] : s;
+    }
+}
+
+// class indices / weights of a dense [rows x S] state that is zero or one-hot per factor
+__device__ __forceinline__ void state_to_indices(const CatGeo& g, const float* __restrict__ dense, size_t ld, int row0, int rows,
+                                                 int* __restrict__ sidx_l, float* __restrict__ sw_l) {
+    for (int i = bd_tid(); i < 16 * g.D; i += blockDim.x) {
+        const int row = i / g.D, f = i - row * g.D;
+        float best = 0.f;
+        int arg = 0;
+        if (row0 + row < rows) {
+            const float* p = dense + (size_t)(row0 + row) * ld + f * g.C;
+            for (int c = 0; c < g.C; ++c)
+                if (fabsf(p[c]) > fabsf(best)) { best = p[c]; arg = c; }
+        }
+        sidx_l[i] = arg;
+        sw_l[i] = best;
+    }
+}
+
+// dense one-hot rows (scaled) from the indices: dst rows are global, row stride ld.  One thread per (row, factor) writes
+// its C floats (16-byte stores when C and the row stride allow): no per-element index arithmetic.
+__device__ __forceinline__ void write_onehot(const CatGeo& g, const int* __restrict__ sidx_l, const float* __restrict__ sw_l,
+                                             const float* __restrict__ scale_l, float* __restrict__ dst_row0, size_t ld,
+                                             int rows_valid) {
+    const bool vec = (g.C & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)dst_row0) & 15) == 0;
+    for (int i = bd_tid(); i < 16 * g.D; i += blockDim.x) {
+        const int row = i / g.D, f = i - row * g.D;
+        if (row >= rows_valid) continue;
+        const int hot = sidx_l[i];
+        float v = sw_l[i];
+        if (scale_l) v *= scale_l[row];
+        float* p = dst_row0 + (size_t)row * ld + f * g.C;
+        if (vec) {
+            for (int c = 0; c < g.C; c += 4) {
+                floatx4 o = floatx4{0.f, 0.f, 0.f, 0.f};
+                if ((hot & ~3) == c) o[hot & 3] = v;
+                *reinterpret_cast<floatx4*>(p + c) = o;
+            }
+        } else {
+            for (int c = 0; c < g.C; ++c) p[c] = (c == hot) ? v : 0.f;
+        }
+    }
+}
+
 }  // namespace bd

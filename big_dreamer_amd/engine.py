@@ -818,8 +818,31 @@ class DreamerEngine:
             a.sv_s, a.sv_x = ptr(self.buf("sv_s", M, d.S)), ptr(self.buf("sv_x", M, d.Be))
             a.sv_gates, a.sv_q = ptr(self.buf("sv_gates", M, 4 * d.Be)), ptr(self.buf("sv_q", M, d.Hd))
         with self.span("observe_fwd"):
-            cabi.check(lib.bd_observe_cat_forward(C.byref(a), cabi.stream()))
+            Cm = self._cat_cluster(B)
+            if Cm:
+                ws = self._cat_cluster_ws(B, Cm)
+                cabi.check(lib.bd_observe_cat_forward_cluster(C.byref(a), Cm, ptr(ws), ws.numel(), cabi.stream()))
+            else:
+                cabi.check(lib.bd_observe_cat_forward(C.byref(a), cabi.stream()))
         return feat, logits, logits
+
+    def _cat_cluster(self, B: int) -> int:
+        """Members per 16-row tile of the Categorical cluster observe scan (csrc/observe_cat_cluster.hip), 0 = use the
+        one-workgroup-per-tile kernels: same rule as _cluster_ok (tiles * Cm one-per-CU members leave half the chip to the
+        other pipeline streams)."""
+        if not self.use_obs_cluster:
+            return 0
+        d = self.d
+        return int(lib.bd_observe_cat_cluster_size(B, d.Be, d.cat_D, d.cat_C, int(os.environ.get("BD_OBS_CLUSTER_MAX_WGS", "128"))))
+
+    def _cat_cluster_ws(self, B: int, Cm: int) -> torch.Tensor:
+        d = self.d
+        need = int(lib.bd_observe_cat_cluster_ws_floats(B, d.Be, d.Hd, d.cat_D, Cm))
+        off = int(lib.bd_observe_cluster_err_offset(B))
+        if self._obs_ws is None or self._obs_ws.numel() < need or self._obs_err_off != off:
+            self._obs_ws = torch.zeros(need, dtype=torch.float32, device=self.dev)     # zero: flags AND the sticky error word
+            self._obs_err_off = off
+        return self._obs_ws
 
     def _buf_u8(self, name: str, *shape) -> torch.Tensor:
         t = self._buf.get(name)
@@ -1337,7 +1360,12 @@ class DreamerEngine:
             b.dfeat, b.dpost_logits = ptr(dfeat), ptr(dqm)
             b.d_embed_pre, b.d_gi, b.d_gh, b.d_q1_pre, b.d_q2_out = ptr(d_e), ptr(d_gi), ptr(d_gh), ptr(d_q1), ptr(d_q2)
             with self.span("observe_bwd"):
-                cabi.check(lib.bd_observe_cat_backward(C.byref(b), st))
+                Cm = self._cat_cluster(B)
+                if Cm:
+                    ws_c = self._cat_cluster_ws(B, Cm)
+                    cabi.check(lib.bd_observe_cat_backward_cluster(C.byref(b), Cm, ptr(ws_c), ws_c.numel(), st))
+                else:
+                    cabi.check(lib.bd_observe_cat_backward(C.byref(b), st))
         else:
             self._observe_backward_gaussian(T, B, init_belief, nonterm, noise, feat, qs, dfeat, dqm, dqs, d_e, d_gi, d_gh,
                                             d_q1, d_q2, st)

@@ -425,6 +425,20 @@ typedef struct {
 } bd_observe_cat_bwd_args;
 int bd_observe_cat_backward(const bd_observe_cat_bwd_args* a, void* stream);
 
+/* Cluster variant of the Categorical observe scan (csrc/observe_cat_cluster.hip): Cm = bd_observe_cat_cluster_size(B, Be,
+ * D, C, max_wgs) workgroups, one per CU, share each 16-row tile -- GRU column blocks and groups of D / Cm factors of the
+ * posterior head are split over the members, two hand-offs per time step through `ws` (forward: new belief, sampled class
+ * indices; backward: d posterior-hidden all-reduce, [belief-gradient carry | d embed pre-activation]).  Same arguments,
+ * same results as bd_observe_cat_forward / bd_observe_cat_backward (TransitionModel.forward, src/models.py:191-299,
+ * Categorical branches).  cluster size 0 = shape not supported or tiles * Cm > max_wgs: use the one-workgroup-per-tile
+ * calls.  `ws`: bd_observe_cat_cluster_ws_floats(B, Be, Hd, D, Cm) floats, zero-filled ONCE by the caller; header, sticky
+ * error word (bd_observe_cluster_err_offset / bd_observe_cluster_status) and time-out behaviour as for
+ * bd_observe_forward_cluster. */
+int bd_observe_cat_cluster_size(int B, int Be, int D, int C, int max_wgs);
+size_t bd_observe_cat_cluster_ws_floats(int B, int Be, int Hd, int D, int Cm);
+int bd_observe_cat_forward_cluster(const bd_observe_cat_fwd_args* a, int Cm, float* ws, size_t ws_floats, void* stream);
+int bd_observe_cat_backward_cluster(const bd_observe_cat_bwd_args* a, int Cm, float* ws, size_t ws_floats, void* stream);
+
 typedef struct {
     int N, Hm, Be, D, C, A, Hd, n_samples;
     const float* w_embed_sT; const float* w_embed_a; const float* b_embed;

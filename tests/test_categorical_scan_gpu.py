@@ -24,7 +24,7 @@ def _rel(name, got, want, atol, rtol, report):
     assert_close(name, got, want, atol, rtol)
 
 
-def _setup(name):
+def _setup(name, cluster=True):
     from big_dreamer_amd.engine import DreamerEngine
     from oracle import dreamer_oracle as O
     d, seed, hp, full = CAT_CASES[name]
@@ -32,17 +32,22 @@ def _setup(name):
     P, batch, noise = synth.make_params(d, seed), synth.make_batch(d, seed), synth.make_noise(d, seed)
     check_fingerprints(g, P, batch, noise)
     eng = DreamerEngine(d, hp, "cuda", params=P)
+    # 32 x 32 latents run the multi-CU cluster observe scan by default (csrc/observe_cat_cluster.hip); cluster=False
+    # selects the one-workgroup-per-tile kernels (csrc/scan_cat.hip).  Ragged factor shapes (3 x 5) always use the latter.
+    if not cluster:
+        eng.use_obs_cluster = False
+    assert bool(eng._cat_cluster(d.B)) == (cluster and d.cat_D == 32), "observe-scan kernel selection"
     od = O.OracleDreamer(P, dict(hp, planning_horizon=d.H, categorical=(d.cat_D, d.cat_C)))
     return d, seed, hp, full, g, P, batch, noise, eng, od
 
 
-@pytest.mark.parametrize("name", list(CAT_CASES))
-def test_categorical_forward_pieces(name):
+@pytest.mark.parametrize("name,cluster", [(n, True) for n in CAT_CASES] + [("cat_32", False), ("cat_pixel_32", False)])
+def test_categorical_forward_pieces(name, cluster):
     """Observe scan (posterior logits, exact one-hot samples, beliefs), batched prior head, imagination rollout
     (beliefs, exact sampled states, prior logits, entropy), reward / value heads on [h; one-hot s], lambda-returns."""
     from big_dreamer_amd import _cabi as cabi
     from oracle import dreamer_oracle as O
-    d, seed, hp, full, g, P, batch, noise, eng, od = _setup(name)
+    d, seed, hp, full, g, P, batch, noise, eng, od = _setup(name, cluster)
     cat = (d.cat_D, d.cat_C)
     tb = {k: torch.as_tensor(v) for k, v in batch.items()}
     tn = {k: torch.as_tensor(v) for k, v in noise.items()}
@@ -98,12 +103,13 @@ def test_categorical_forward_pieces(name):
         print("\n".join(rep))
 
 
-@pytest.mark.parametrize("name", list(CAT_CASES))
-def test_categorical_train_steps_vs_oracle_and_golden(name):
+@pytest.mark.parametrize("name,cluster", [(n, True) for n in CAT_CASES] + [("cat_32", False), ("cat_32_v2", False),
+                                                                          ("cat_pixel_32", False)])
+def test_categorical_train_steps_vs_oracle_and_golden(name, cluster):
     """Two whole train steps with Categorical latents: logs, clipped gradients of every parameter tensor, gradient norms,
     post-Adam weights -- against the oracle and against the reference's own run (golden)."""
     from oracle import dreamer_oracle as O
-    d, seed, hp, full, g, P, batch, noise, eng, od = _setup(name)
+    d, seed, hp, full, g, P, batch, noise, eng, od = _setup(name, cluster)
     db = _dev(batch)
     rep = []
     try:
@@ -115,6 +121,7 @@ def test_categorical_train_steps_vs_oracle_and_golden(name):
                 od.update_critic()
                 eng.update_critic()
             torch.cuda.synchronize()
+            eng.cluster_status(d.B)          # no cluster member timed out waiting for its peers
             for k, v in ologs.items():
                 tol = (2e-4, 2e-4) if k in ("policy_entropy", "actor_loss") else (2e-5, 5e-5)
                 _rel(f"s{step}.{k}", logs[k], v, tol[0], tol[1], rep)
@@ -255,6 +262,8 @@ def test_categorical_full_size_step_vs_oracle(which):
     ologs = od.train_step(batch, nz)
     logs = eng.train_step(_dev(batch), _dev(nz))
     torch.cuda.synchronize()
+    assert eng._cat_cluster(d.B) == 16, "batch 100 = 7 row tiles x 16 members: the cluster observe scan is the product path"
+    eng.cluster_status(d.B)
     rep = []
     try:
         for k, v in ologs.items():
@@ -283,3 +292,32 @@ def test_categorical_full_size_step_vs_oracle(which):
                 _rel(f"param.{mod}.{k}", eng.W(mod, k).cpu().numpy(), p.detach().numpy(), 2e-5, 1e-5, rep)
     finally:
         print("\n".join(rep[-160:]))
+
+
+def test_categorical_cluster_scan_matches_one_workgroup_scan():
+    """The multi-CU cluster observe scan (csrc/observe_cat_cluster.hip: GRU column blocks and factor groups of the head
+    split over 16 members per tile, two hand-offs per step) against the one-workgroup-per-tile scan (csrc/scan_cat.hip) at
+    the full model size (belief / hidden 200, 32 x 32 latents), batch 40 = three row tiles, one ragged: identical sampled
+    states, beliefs / logits / every weight after a whole train step to fp32 summation-order noise."""
+    from big_dreamer_amd.engine import DreamerEngine
+    d = synth.Dims(B=40, L=9, H=4, S=1024, cat_D=32, cat_C=32, A=3, O=7)
+    P, batch, nz = synth.make_params(d, 81), synth.make_batch(d, 81), synth.make_noise(d, 81)
+    out = {}
+    for cluster in (True, False):
+        eng = DreamerEngine(d, dict(free_nats=0.0), "cuda", params=P)
+        eng.use_obs_cluster = cluster
+        assert bool(eng._cat_cluster(d.B)) == cluster
+        logs = eng.train_step(_dev(batch), _dev(nz))
+        torch.cuda.synchronize()
+        eng.cluster_status(d.B)
+        out[cluster] = (logs, {k: eng._buf[k].clone() for k in ("p0_feat", "post_logits", "p0_sidx", "d_embed_pre", "d_q1_pre", "d_q2_out")},
+                        {g: eng.groups[g].flat.clone() for g in ("model", "actor", "critic")})
+    (la, ba, wa), (lb, bb, wb) = out[True], out[False]
+    assert torch.equal(ba["p0_sidx"], bb["p0_sidx"]), "sampled posterior classes differ between the two scans"
+    for k in ("p0_feat", "post_logits", "d_embed_pre", "d_q1_pre", "d_q2_out"):
+        scale = float(bb[k].abs().max()) + 1e-12
+        assert float((ba[k] - bb[k]).abs().max()) <= 2e-5 * scale + 1e-7, (k, float((ba[k] - bb[k]).abs().max()), scale)
+    for g in wa:
+        assert float((wa[g] - wb[g]).abs().max()) < 2e-6, g
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-5 + 1e-5 * abs(lb[k]), (k, la[k], lb[k])
