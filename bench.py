@@ -393,7 +393,7 @@ def main():
                                     + f", belief=200 hidden=200 embedding=1024, batch={d.B}/GPU (800/8) chunk=50 H=15")
                        if args.categorical else
                        ("BASELINE.json configs[2]: 64x64 pixel-obs Dreamer train_step (conv stacks on "
-                                    + ("this library's gather-GEMM kernels" if eng.conv_hip else "MIOpen") + "), "
+                                    "this library's gather-GEMM kernels), "
                                     "belief=200 state=30 hidden=200 embedding=1024 action=17, batch=50/GPU chunk=50 H=15")
                        if args.pixel else
                        ("BASELINE.json configs[1]: state-obs Dreamer train_step, belief=200 state=30 "

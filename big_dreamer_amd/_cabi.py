@@ -188,6 +188,7 @@ _SIGS = {
     "bd_actor_entropy": (I32, [P, P, P, I32, I32, I32, I32, P]),
     "bd_imagine_backward": (I32, [C.POINTER(ImagineBwdArgs), P]),
     "bd_lambda_return_forward": (I32, [P, P, I32, I32, F32, F32, P, P]),
+    "bd_gemm_nt": (I32, [P, I32, P, I32, P, I32, I32, I32, I32, I32, P]),
     "bd_categorical_head_forward": (I32, [P, P, I32, I32, I32, P, P, P]),
     "bd_categorical_head_backward": (I32, [P, P, I32, I32, I32, P, P]),
     "bd_kl_categorical_forward": (I32, [P, P, I32, I32, I32, F32, I32, P, I32, P, P]),

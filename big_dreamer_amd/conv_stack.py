@@ -6,9 +6,8 @@ ObservationModel (src/models.py:319-362): Linear(Be+S, E), ConvT(E,128,k5,s2)+EL
 
 Activations are NHWC; conv weights are stored (d0, ky, kx, d1) (engine.ParamGroup).  Forward, dgrad and the weight
 gradients of every layer are kernels of this library (bd_conv_gemm patterns F / T, bd_mlp_forward / backward for
-the Linear-shaped layers, bd_wgrad_grouped with gathered windows); the one exception is the dgrad of the 1x1 -> 5x5
-transposed convolution, a plain (M x 3200) x (3200 x E) GEMM whose K does not fit the LDS-resident row tiles: rocBLAS
-through torch.mm.  Results match the reference's autograd path to the fp32 tolerance of tests/test_hip_parity.py
+the Linear-shaped layers, bd_wgrad_grouped with gathered windows, and bd_gemm_nt (csrc/gemm.hip) for the dgrad of the
+1x1 -> 5x5 transposed convolution, a plain (M x 3200) x (3200 x E) GEMM whose K does not fit the LDS-resident row tiles).  Results match the reference's autograd path to the fp32 tolerance of tests/test_hip_parity.py
 (pixel golden cases).
 """
 from __future__ import annotations
@@ -165,7 +164,9 @@ class ConvStacks:
         wb.add(l0, self.E, g, 25 * 128, M, self.E, 25 * 128, G("decoder.2.weight"), 25 * 128, None)
         self._colsum(wb, g, M * 25, 128, G("decoder.2.bias"))
         gl0 = e.buf("cv_gl0", M, self.E)
-        torch.mm(g.view(M, 25 * 128), e.Ws("observation_model", "decoder.2.weight").view(self.E, 25 * 128).t(), out=gl0)
+        # d l0 = g W^T with the stored matrix W (ci, (ky, kx, co)) as it lies in the parameter buffer: a plain K = 3200 GEMM
+        cabi.check(lib.bd_gemm_nt(ptr(g), 25 * 128, ptr(e.Ws("observation_model", "decoder.2.weight")), 25 * 128, ptr(gl0),
+                                  self.E, M, self.E, 25 * 128, 0, cabi.stream()))
         # Linear(Be+S, E)
         wb.add(gl0, self.E, feat, F, M, self.E, F, e.G("observation_model", "decoder.0.weight"), F,
                e.G("observation_model", "decoder.0.bias"))

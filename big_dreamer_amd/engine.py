@@ -21,7 +21,6 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
-import torch.nn.functional as Fnn
 
 from . import _cabi as cabi
 from .parallel import DataParallel
@@ -205,6 +204,8 @@ class WgradBatch:
 
     def run(self) -> None:
         eng = self.eng
+        if not self.items:
+            return
         key = tuple(self.items)
         hit = self._cache.get(key)
         if hit is None:
@@ -240,7 +241,7 @@ class DreamerEngine:
     def __init__(self, dims: Dims, hp: Optional[dict] = None, device="cuda", params: Optional[dict] = None,
                  world_size: int = 1, process_group=None, phase_groups: Optional[dict] = None):
         self.d = dims
-        self.pixel = bool(dims.pixel)   # conv encoder / decoder through MIOpen (torch), everything else HIP kernels
+        self.pixel = bool(dims.pixel)   # 64x64 pixel observations: conv encoder / decoder on csrc/conv.hip (conv_stack.py)
         self.hp = dict(DEFAULT_HP)
         if hp:
             self.hp.update({k: v for k, v in hp.items() if k in self.hp})
@@ -252,13 +253,12 @@ class DreamerEngine:
                                process_group, phase_groups)
         d = dims
         shapes = param_shapes(d)
-        # pixel mode: the conv stacks run on this library's gather-GEMM kernels (csrc/conv.hip, conv_stack.py;
-        # 17.9 ms/step at configs[2], 18.9 serial); BD_CONV=miopen keeps them on MIOpen through torch autograd, the
-        # measured incumbent (17.9 ms/step, 20.0 serial) -- see DESIGN.md section 5, row R11
-        self.conv_hip = self.pixel and os.environ.get("BD_CONV", "hip") != "miopen"
+        # pixel mode: the conv stacks run on this library's gather-GEMM kernels (csrc/conv.hip, conv_stack.py) and their
+        # weights are STORED (d0, ky, kx, d1) (ParamGroup).  (The MIOpen / torch-autograd comparator of rounds 1-2 is a test
+        # helper now: tests/torch_conv_stacks.py injects it through the same `self.conv` interface.)
         self.groups = {
             "model": ParamGroup([(m, n, s) for m in model_modules(d) for n, s in shapes[m]], self.dev,
-                                conv_storage=self.conv_hip),
+                                conv_storage=self.pixel),
             "actor": ParamGroup([("actor", n, s) for n, s in shapes["actor"]], self.dev),
             "critic": ParamGroup([("critic", n, s) for n, s in shapes["critic"]], self.dev),
             "critic_target": ParamGroup([("critic_target", n, s) for n, s in shapes["critic"]], self.dev, False),
@@ -341,7 +341,7 @@ class DreamerEngine:
         self._timer_events: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
         self._build_pack_tables()
         self.conv = None
-        if self.conv_hip:
+        if self.pixel:
             from .conv_stack import ConvStacks
             self.conv = ConvStacks(self)
         for g in ("model", "actor", "critic", "critic_target"):
@@ -388,7 +388,7 @@ class DreamerEngine:
         return self.groups[self._mod_group[mod]].g[(mod, name)]
 
     def Ws(self, mod: str, name: str) -> torch.Tensor:
-        """Contiguous STORAGE view of a parameter (differs from W() for conv tensors in conv_hip mode)."""
+        """Contiguous STORAGE view of a parameter (differs from W() for conv tensors)."""
         return self.groups[self._mod_group[mod]].ps[(mod, name)]
 
     def Gs(self, mod: str, name: str) -> torch.Tensor:
@@ -701,50 +701,21 @@ class DreamerEngine:
         self.mlp_forward(M, obs2d, d.O, d.O, layers, acts + [emb, None], pre, d.Hd)
         return emb, pre
 
-    # ---- pixel observations: conv stacks on MIOpen through torch (the measured incumbent) ----
-    def _leaf_params(self, mod: str):
-        """Fresh autograd leaves aliasing the flat parameter buffer (name -> tensor), reference order."""
-        g = self.groups[self._mod_group[mod]]
-        return {n: g.p[(m, n)].detach().requires_grad_(True) for (m, n, _) in g.specs if m == mod}
-
+    # ---- pixel observations: the conv stacks (conv_stack.ConvStacks; same interface: tests/torch_conv_stacks.py) ----
     def encode_pixels(self, obs4d: torch.Tensor, grad: bool = True):
-        """CnnImageEncoder (src/models.py:527-564) on (M,3,64,64) + the hoisted posterior projection (HIP)."""
+        """CnnImageEncoder (src/models.py:527-564) on (M,3,64,64) + the hoisted posterior projection.  grad=False: API use
+        (separate activation buffers, nothing kept for a backward)."""
         d = self.d
         M = obs4d.shape[0]
-        if self.conv is not None:        # hand-written gather-GEMM stack (conv_stack.py)
-            emb = self.conv.encode(obs4d.float(), tag="" if grad else "api_")
-            pre = self.buf("pre_emb" if grad else "api_cv_pre_emb", M, d.Hd)
-            self.mlp_forward(M, emb, d.E, d.E, [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)], None, pre, d.Hd)
-            return emb, pre
-        with torch.set_grad_enabled(grad):
-            w = self._leaf_params("encoder") if grad else self.state_dict("encoder")
-            x = obs4d
-            for i in range(4):
-                x = Fnn.elu(Fnn.conv2d(x, w[f"model.{2 * i}.weight"], w[f"model.{2 * i}.bias"], stride=2))
-            x = x.flatten(1)
-            if "model.9.weight" in w:
-                x = Fnn.linear(x, w["model.9.weight"], w["model.9.bias"])
-        self._enc_graph = (x, w) if grad else None
-        emb = x.detach().contiguous()
-        pre = self.buf("pre_emb", M, d.Hd)
+        emb = self.conv.encode(obs4d.float(), tag="" if grad else "api_")
+        pre = self.buf("pre_emb" if grad else "api_cv_pre_emb", M, d.Hd)
         self.mlp_forward(M, emb, d.E, d.E, [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)], None, pre, d.Hd)
         return emb, pre
 
-    def decode_pixels(self, feat: torch.Tensor, grad: bool = True) -> torch.Tensor:
-        """ObservationModel (src/models.py:319-362): (M, Be+S) -> (M,3,64,64)."""
-        if self.conv is not None:        # API use (ObservationModel.forward): NHWC prediction back to the reference's NCHW
-            from . import conv as _conv
-            return _conv.to_nchw(self.conv.decode(feat.contiguous().float(), tag="api_"))
-        with torch.set_grad_enabled(grad):
-            w = self._leaf_params("observation_model") if grad else self.state_dict("observation_model")
-            f = feat.detach().requires_grad_(grad)
-            x = Fnn.linear(f, w["decoder.0.weight"], w["decoder.0.bias"]).view(feat.shape[0], -1, 1, 1)
-            for idx in (2, 4, 6, 8):
-                x = Fnn.conv_transpose2d(x, w[f"decoder.{idx}.weight"], w[f"decoder.{idx}.bias"], stride=2)
-                if idx != 8:
-                    x = Fnn.elu(x)
-        self._dec_graph = (x, w, f) if grad else None
-        return x
+    def decode_pixels(self, feat: torch.Tensor) -> torch.Tensor:
+        """ObservationModel (src/models.py:319-362) for API callers: (M, Be+S) -> (M,3,64,64) in the reference's NCHW."""
+        from . import conv as _conv
+        return _conv.to_nchw(self.conv.decode(feat.contiguous().float(), tag="api_"))
 
     def observe(self, actions, nonterm, pre_emb, eps_post, init_belief, init_state, T: int, B: int, save: bool = True,
                 tag: str = "", prior_only: bool = False, feat_tag: str = ""):
@@ -1249,11 +1220,9 @@ class DreamerEngine:
         cat = d.categorical
         with self.span("wm_heads_fwd"):
             _, pm, ps = self.prior_head(feat, N, None if cat else noise["obs_prior"])
-            if self.conv is not None:
+            if self.pixel:
                 om_out, om_acts, om_layers = self.conv.decode(feat).view(N, d.O), None, None
                 obs_t = self.conv.acts_enc[0].view(N, d.O)      # the same images in the NHWC order of the prediction
-            elif self.pixel:
-                om_out, om_acts, om_layers = self.decode_pixels(feat).detach().view(N, d.O), None, None
             else:
                 om_out, om_acts, om_layers = self.dense_forward("observation_model", "obs", "om", feat, F, N, d.O,
                                                                 sidx=self._buf[feat_tag + "sidx"] if cat else None)
@@ -1299,7 +1268,7 @@ class DreamerEngine:
         # ---- backward of the world model ----
         dfeat = self.buf("dfeat", N, F)
         rw_dpre = [self.buf(f"rw_dpre{l}", N, d.Hd) for l in range(DENSE_LAYERS)] + [d_rw]
-        if self.conv is not None:
+        if self.pixel:
             self.mlp_backward(N, d_rw, 1, rw_layers, rw_acts + [None], rw_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F)
             with self.span("decoder_bwd"):
                 # the decoder's weight-gradient GEMMs (60 % of the pass) are ready here: they run on their own stream
@@ -1308,16 +1277,6 @@ class DreamerEngine:
                 self._s_early.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self._s_early):
                     self._wbatch["model_early"].run()
-        elif self.pixel:
-            self.mlp_backward(N, d_rw, 1, rw_layers, rw_acts + [None], rw_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F)
-            with self.span("decoder_bwd"):
-                pred, wdec, fleaf = self._dec_graph
-                names = list(wdec)
-                grads = torch.autograd.grad(pred, [wdec[n] for n in names] + [fleaf], d_om.view_as(pred))
-                for n, g in zip(names, grads[:-1]):
-                    self.G("observation_model", n).copy_(g)
-                dfeat.add_(grads[-1])
-                self._dec_graph = None
         else:
             om_dpre = [self.buf(f"om_dpre{l}", N, d.Hd) for l in range(DENSE_LAYERS)] + [d_om]
             self.mlp_backward(N, d_om, d.O, om_layers, om_acts + [None], om_dpre[:-1] + [None], din0=dfeat, ld0=F, w0=F)
@@ -1407,14 +1366,7 @@ class DreamerEngine:
             self.mlp_backward(N, d_q1, d.Hd, [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)], [None], [None], din0=d_emb, ld0=d.E,
                               w0=d.E)
             with self.span("encoder_bwd"):
-                if self.conv is not None:
-                    self.conv.backward_encoder(d_emb, self._wbatch["model"])
-                else:
-                    x, wenc = self._enc_graph
-                    names = list(wenc)
-                    for n, g in zip(names, torch.autograd.grad(x, [wenc[n] for n in names], d_emb)):
-                        self.G("encoder", n).copy_(g)
-                    self._enc_graph = None
+                self.conv.backward_encoder(d_emb, self._wbatch["model"])
         else:
             enc_layers = self._dense_spec("encoder", "enc", d.O, d.E) + [("q1e", None, d.Hd, d.E, cabi.ACT_NONE)]
             enc_acts = [self._buf[f"enc_act{l}"] for l in range(DENSE_LAYERS)]
@@ -1443,12 +1395,12 @@ class DreamerEngine:
         self._dense_wgrads(wb, "reward_model", N, rw_dpre, feat, F, rw_acts, dense_sizes(F, 1))
         if self._dc_wgrad is not None:
             self._dense_wgrads(wb, "discount_model", N, self._dc_wgrad[0], feat, F, self._dc_wgrad[1], dense_sizes(F, 1))
-        if not self.pixel:      # (pixel mode: conv weight gradients came from MIOpen above)
+        if not self.pixel:      # (pixel mode: the conv stacks queued their weight gradients themselves)
             self._dense_wgrads(wb, "observation_model", N, om_dpre, feat, F, om_acts, dense_sizes(F, d.O))
             self._dense_wgrads(wb, "encoder", N, enc_dpre, obs_t, d.O, enc_acts, dense_sizes(d.O, d.E))
         with self.span("wgrad_model"):
             wb.run()
-        if self.conv is not None:
+        if self.pixel:
             torch.cuda.current_stream().wait_stream(self._s_early)      # decoder weight gradients (queued above)
         if self.pipeline and self._ev_bh_wm_free is not None:
             # the previous step's imagination / reward-head kernels may still be reading the weights Adam overwrites

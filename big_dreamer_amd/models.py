@@ -216,7 +216,7 @@ class ActorModel(_EngineBacked):
 
 class CnnImageEncoder(_EngineBacked):
     """src/models.py:527-564: 4 x (Conv2d k4 s2 + ELU), Flatten, Identity | Linear(1024, E) -- ``model.{0,2,4,6[,9]}``.
-    The convolutions run on MIOpen through torch (measured incumbent)."""
+    The convolutions run on this library's gather-GEMM kernels (csrc/conv.hip through conv_stack.ConvStacks)."""
 
     def __init__(self, embedding_size: int, activation: str = "ELU", *, engine: DreamerEngine):
         super().__init__()
@@ -253,7 +253,7 @@ class ObservationModel(_EngineBacked):
         self._eng.join()      # order after any queued pipeline work (engine.train_step)
         lead = belief.shape[:-1]
         x = torch.cat([belief, state], dim=-1).reshape(-1, belief.shape[-1] + state.shape[-1]).contiguous().float()
-        return self._eng.decode_pixels(x, grad=False).view(*lead, 3, 64, 64).clone()
+        return self._eng.decode_pixels(x).view(*lead, 3, 64, 64).clone()
 
 
 def encoder_for(engine: DreamerEngine, observation_size: int, hidden_size: int, embedding_size: int) -> DenseModel:

@@ -350,6 +350,13 @@ int bd_lambda_return_forward(const float* reward, const float* value, int Hm, in
 int bd_lambda_return_backward(const float* dreturns, float dret_const, int Hm, int N, float discount,
                               float lambda_, float* dreward, float* dvalue, void* stream);
 
+/* ---- plain GEMM  C[M x N] (+)= A[M x K] B[N x K]^T  (csrc/gemm.hip; fp32 MFMA, exact fp32 products and sums).
+ * The pixel decoder's one plain GEMM: the dgrad of ConvTranspose2d(E -> 128, k5, s2) on a 1 x 1 map
+ * (src/models.py:338-341), d l0[M x E] = g[M x 3200] W[E x 3200]^T.  Any K / leading dimensions / alignment (16-byte
+ * loads per operand where its base, leading dimension and K allow them). */
+int bd_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, int accumulate,
+               void* stream);
+
 /* ---- Categorical latents: CategoricalBeliefModel tail (src/models.py:108-117) and the Categorical branch of
  * Dreamer._kl_loss (src/dreamer.py:102-106,131-144).  logits / state / probs are [rows x D*C], D groups of C classes.
  * Forward: probs = softmax(logits) per group; state = one_hot(argmax(probs / q_noise)) with q_noise ~ Exp(1), which is

@@ -139,3 +139,31 @@ def test_gathered_wgrad_matches_conv_weight_gradients(Cin, Cout, k, size):
     gyts = conv.to_nhwc(gyt)
     conv.run_wgrad([conv.wgrad_desc(xts, Cout, gyts, imgs, OH, OH, HT, HT, Cin, k, dWt, None)])
     _close(dWt.permute(0, 3, 1, 2), gwt_ref, 1e-4)
+
+
+@pytest.mark.parametrize("M,N,K,acc", [(2450, 1024, 3200, False), (37, 70, 52, False), (333, 200, 1024, True), (16, 64, 32, False),
+                                       (50, 33, 45, True)])
+def test_plain_gemm_nt_matches_cpu_fp32(M, N, K, acc):
+    """bd_gemm_nt (csrc/gemm.hip): C (+)= A B^T -- the decoder's K = 3200 dgrad GEMM (first case: configs[2] sizes, 256
+    workgroups of 160 x 64) and ragged shapes / every rows-per-workgroup variant, against a CPU fp32 matmul."""
+    from big_dreamer_amd import _cabi as cabi
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K + 4, generator=g)[:, :K]              # lda > K
+    B = torch.randn(N, K, generator=g) / K ** 0.5
+    C0 = torch.randn(M, N + 3, generator=g)
+    Ad = A.cuda()
+    Ad_full = torch.zeros(M, K + 4, device="cuda")
+    Ad_full[:, :K] = Ad
+    # B at a float offset of 1 when K is odd-ish (a weight inside the flat parameter buffer): the scalar-load path
+    Bbuf = torch.zeros(N * K + 1, device="cuda")
+    Bd = Bbuf[K % 2:K % 2 + N * K].view(N, K)
+    Bd.copy_(B)
+    Cd = C0.cuda().contiguous()
+    cabi.check(cabi.lib.bd_gemm_nt(Ad_full.data_ptr(), K + 4, Bd.data_ptr(), K, Cd.data_ptr(), N + 3, M, N, K, int(acc),
+                                   cabi.stream()))
+    torch.cuda.synchronize()
+    ref = A.double() @ B.double().t() + (C0[:, :N].double() if acc else 0)
+    got = Cd.cpu()
+    assert torch.equal(got[:, N:], C0[:, N:]), "columns beyond N were written"
+    err = float((got[:, :N].double() - ref).abs().max())
+    assert err <= 2e-5 * float(ref.abs().max()) + 1e-6, err

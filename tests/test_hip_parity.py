@@ -103,12 +103,16 @@ def test_train_steps_vs_oracle_and_golden(name, cluster, monkeypatch):
     """Two whole train steps: losses, clipped gradients, gradient norms, post-Adam weights -- with the observe
     scan run by the multi-CU cluster kernels (default) and by the single-workgroup kernels."""
     from oracle import dreamer_oracle as O
-    if cluster == "miopen":         # the pixel conv stacks on MIOpen through torch autograd instead of conv.hip
-        monkeypatch.setenv("BD_CONV", "miopen")
+    torch_convs = cluster == "miopen"
+    if torch_convs:
         cluster = True
     d, seed, hp, full, g, P, batch, noise, eng = _setup(name, cluster)
     if d.pixel:
-        assert (eng.conv is not None) == (eng.conv_hip), "conv path selection"
+        from big_dreamer_amd.conv_stack import ConvStacks
+        assert isinstance(eng.conv, ConvStacks), "the product engine has ONE pixel path: csrc/conv.hip"
+    if torch_convs:                 # comparator (test helper): the conv stacks on MIOpen through torch autograd
+        from tests.torch_conv_stacks import TorchConvStacks
+        eng.conv = TorchConvStacks(eng)
     od = O.OracleDreamer(P, dict(hp, planning_horizon=d.H))
     db = _dev(batch)
     rep = []
