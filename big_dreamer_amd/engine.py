@@ -57,7 +57,10 @@ class ParamGroup:
     def __init__(self, specs: List[Tuple[str, str, Tuple[int, ...]]], device, with_opt: bool = True,
                  conv_storage: bool = False):
         self.specs = specs
-        n = sum(int(np.prod(s)) for _, _, s in specs)
+        # every tensor starts on a 16-byte boundary of the flat buffers (pad floats stay zero: zero gradient, zero Adam
+        # update): 16-byte vector loads and LDS-DMA of a weight matrix as it lies in the buffer (csrc/gemm.hip)
+        al = lambda k: (k + 3) & ~3
+        n = sum(al(int(np.prod(s))) for _, _, s in specs)
         self.numel = n
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
         self.grad = torch.zeros(n, dtype=torch.float32, device=device) if with_opt else None
@@ -83,7 +86,7 @@ class ParamGroup:
             self.ps[(mod, name)], self.p[(mod, name)] = views(self.flat)
             if with_opt:
                 self.gs[(mod, name)], self.g[(mod, name)] = views(self.grad)
-            off += k
+            off += al(k)
 
     def logical(self, buf: torch.Tensor, mod: str, name: str) -> torch.Tensor:
         """View of `buf` (a flat buffer laid out like `flat`: grad, m, v) with the reference's shape of (mod, name)."""

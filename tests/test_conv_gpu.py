@@ -142,7 +142,7 @@ def test_gathered_wgrad_matches_conv_weight_gradients(Cin, Cout, k, size):
 
 
 @pytest.mark.parametrize("M,N,K,acc", [(2450, 1024, 3200, False), (37, 70, 52, False), (333, 200, 1024, True), (16, 64, 32, False),
-                                       (50, 33, 45, True)])
+                                       (50, 33, 45, True), (100, 130, 48, False), (200, 64, 16, True), (45, 64, 80, False)])
 def test_plain_gemm_nt_matches_cpu_fp32(M, N, K, acc):
     """bd_gemm_nt (csrc/gemm.hip): C (+)= A B^T -- the decoder's K = 3200 dgrad GEMM (first case: configs[2] sizes, 256
     workgroups of 160 x 64) and ragged shapes / every rows-per-workgroup variant, against a CPU fp32 matmul."""
