@@ -52,6 +52,18 @@ class MlpBwdArgs(C.Structure):
                 ("din1", P), ("ld1", I32), ("w1", I32), ("accumulate", I32)]
 
 
+BD_RNG_MAX_TENSORS = 6
+BD_RNG_NORMAL, BD_RNG_EXPONENTIAL = 0, 1
+
+
+class RngTensor(C.Structure):
+    _fields_ = [("p", P), ("count", C.c_size_t), ("kind", I32), ("stream_id", C.c_uint)]
+
+
+class RngFillArgs(C.Structure):
+    _fields_ = [("n", I32), ("seed", C.c_ulonglong), ("step", C.c_ulonglong), ("t", RngTensor * BD_RNG_MAX_TENSORS)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [("dpre", P), ("ldp", I32), ("act1", P), ("lda1", I32), ("M1", I32), ("act2", P), ("lda2", I32),
                 ("M", I32), ("N", I32), ("K", I32), ("dW", P), ("ldw", I32), ("db", P),
@@ -188,6 +200,9 @@ _SIGS = {
     "bd_actor_entropy": (I32, [P, P, P, I32, I32, I32, I32, P]),
     "bd_imagine_backward": (I32, [C.POINTER(ImagineBwdArgs), P]),
     "bd_lambda_return_forward": (I32, [P, P, I32, I32, F32, F32, P, P]),
+    "bd_rng_fill": (I32, [C.POINTER(RngFillArgs), P]),
+    "bd_philox4x32_10": (I32, [C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    "bd_actor_entropy_rng": (I32, [C.c_ulonglong, C.c_ulonglong, C.c_uint, P, P, I32, I32, I32, I32, P]),
     "bd_gemm_nt": (I32, [P, I32, P, I32, P, I32, I32, I32, I32, I32, P]),
     "bd_categorical_head_forward": (I32, [P, P, I32, I32, I32, P, P, P]),
     "bd_categorical_head_backward": (I32, [P, P, I32, I32, I32, P, P]),

@@ -12,6 +12,7 @@
 #include "bd_device.h"
 #include "bd_host.h"
 #include "bd_scan.h"
+#include "bd_rng.h"
 
 namespace bd {
 
@@ -289,8 +290,11 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
 // One workgroup = 64 / A rows; lane = (row, action dim), the sixteen waves take the draws k = wave, wave + 16, ...;
 // partials are summed in fixed order (deterministic).
 constexpr int kEntParts = 16;
+// RNG = true (perf mode): the draws come from Philox (bd_rng.h) instead of `eps`: sample lane `part` of (row, action dim)
+// generates its ceil(ns / kEntParts) draws four at a time -- the entropy noise tensor never exists in HBM.
+template <bool RNG>
 __global__ __launch_bounds__(64 * kEntParts) void actor_entropy_kernel(const float* __restrict__ eps, float* __restrict__ stats,
-                                                            float* __restrict__ entropy, int Hm, int N, int A, int ns) {
+                                                            float* __restrict__ entropy, int Hm, int N, int A, int ns, Rng rng) {
     __shared__ float red[kEntParts][64][3];
     __shared__ float lpj[64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -303,11 +307,27 @@ __global__ __launch_bounds__(64 * kEntParts) void actor_entropy_kernel(const flo
         const int t = (int)(row / N), n = (int)(row - (long)t * N);
         const float* st = stats + (size_t)row * 4 * A + j;
         const EntConst ec = entropy_const(st[2 * A], st[3 * A]);
-        const float* e0 = eps + ((size_t)t * ns * N + n) * A + j;
-        for (int k = part; k < ns; k += kEntParts) {
-            float l1, d1, d2;
-            entropy_sample(ec, e0[(size_t)k * N * A], l1, d1, d2);
-            lp += l1; dm += d1; ds += d2;
+        if constexpr (RNG) {
+            const int mine = (ns - part + kEntParts - 1) / kEntParts;      // samples k = part, part + kEntParts, ... < ns
+            const uint64_t base = (((uint64_t)row * A + j) * kEntParts + part) * (uint64_t)((ns / kEntParts + 4) / 4);
+            for (int k0 = 0; k0 < mine; k0 += 4) {
+                float e[4];
+                rng_normal4(rng, base + (k0 >> 2), e);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (k0 + q < mine) {
+                        float l1, d1, d2;
+                        entropy_sample(ec, e[q], l1, d1, d2);
+                        lp += l1; dm += d1; ds += d2;
+                    }
+            }
+        } else {
+            const float* e0 = eps + ((size_t)t * ns * N + n) * A + j;
+            for (int k = part; k < ns; k += kEntParts) {
+                float l1, d1, d2;
+                entropy_sample(ec, e0[(size_t)k * N * A], l1, d1, d2);
+                lp += l1; dm += d1; ds += d2;
+            }
         }
     }
     red[part][lane][0] = lp; red[part][lane][1] = dm; red[part][lane][2] = ds;
@@ -589,7 +609,9 @@ static int imagine_forward_scan(const bd_imagine_fwd_args* a, void* stream) {
                "bd_imagine_forward: missing world-model weights");
     BD_REQUIRE(a->w_a0h && a->w_a0s && a->w_a[0] && a->w_a[1] && a->w_a[2] && a->b_a[0] && a->b_a[1] && a->b_a[2] &&
                    a->b_a[3] && a->w_a4m && a->w_a4s && a->b_a4, "bd_imagine_forward: missing actor weights");
-    BD_REQUIRE(a->start_feat && a->eps_action && a->eps_entropy && a->eps_prior, "bd_imagine_forward: missing inputs");
+    BD_REQUIRE(a->start_feat && a->eps_action && a->eps_prior && (a->eps_entropy || a->sv_act_stats),
+               "bd_imagine_forward: missing inputs (eps_entropy may be NULL only with sv_act_stats: the entropy estimate is then "
+               "the caller's bd_actor_entropy / bd_actor_entropy_rng launch)");
     BD_REQUIRE(a->feat && a->prior_std && a->entropy && a->action, "bd_imagine_forward: missing outputs");
     const ImgDims d(a->Be, a->S, a->A, a->Hd);
     // (3*16 + kWaves*16*3)*A floats of small arrays: a multiple of 16 floats, so the scratch stays 16-byte aligned
@@ -607,9 +629,20 @@ int bd_actor_entropy(const float* eps_entropy, float* act_stats, float* entropy,
     BD_REQUIRE(eps_entropy && act_stats && entropy && Hm > 0 && N > 0 && A > 0 && A <= kMaxA && n_samples > 0,
                "bd_actor_entropy: bad arguments");
     const int rows_pb = 64 / A;
-    hipLaunchKernelGGL(actor_entropy_kernel, dim3(cdiv(Hm * N, rows_pb)), dim3(64 * kEntParts), 0, (hipStream_t)stream,
-                       eps_entropy, act_stats, entropy, Hm, N, A, n_samples);
+    hipLaunchKernelGGL(actor_entropy_kernel<false>, dim3(cdiv(Hm * N, rows_pb)), dim3(64 * kEntParts), 0, (hipStream_t)stream,
+                       eps_entropy, act_stats, entropy, Hm, N, A, n_samples, Rng{0, 0, 0, 0});
     BD_CHECK_LAUNCH("bd_actor_entropy");
+    return 0;
+}
+
+int bd_actor_entropy_rng(unsigned long long seed, unsigned long long step, unsigned stream_id, float* act_stats, float* entropy,
+                         int Hm, int N, int A, int n_samples, void* stream) {
+    BD_REQUIRE(act_stats && entropy && Hm > 0 && N > 0 && A > 0 && A <= kMaxA && n_samples > 0, "bd_actor_entropy_rng: bad arguments");
+    const int rows_pb = 64 / A;
+    hipLaunchKernelGGL(actor_entropy_kernel<true>, dim3(cdiv(Hm * N, rows_pb)), dim3(64 * kEntParts), 0, (hipStream_t)stream,
+                       nullptr, act_stats, entropy, Hm, N, A, n_samples,
+                       Rng{(uint32_t)seed, (uint32_t)(seed >> 32), stream_id, (uint32_t)step});
+    BD_CHECK_LAUNCH("bd_actor_entropy_rng");
     return 0;
 }
 
@@ -618,7 +651,7 @@ int bd_imagine_forward_scan(const bd_imagine_fwd_args* a, void* stream) { return
 int bd_imagine_forward(const bd_imagine_fwd_args* a, void* stream) {
     if (int rc = imagine_forward_scan(a, stream)) return rc;
     // with saved actor statistics the scan leaves (mean, std) in their slots 2, 3 and the estimate is one more launch
-    if (a->sv_act_stats != nullptr)
+    if (a->sv_act_stats != nullptr && a->eps_entropy != nullptr)
         return bd_actor_entropy(a->eps_entropy, a->sv_act_stats, a->entropy, a->Hm, a->N, a->A, a->n_samples, stream);
     return 0;
 }

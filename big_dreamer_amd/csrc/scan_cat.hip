@@ -915,7 +915,8 @@ int bd_imagine_cat_forward(const bd_imagine_cat_fwd_args* a, void* stream) {
                    a->b_ih && a->b_hh && a->w_p1 && a->b_p1 && a->w_p2 && a->b_p2 && a->w_a0h && a->w_a0sT && a->w_a[0] &&
                    a->w_a[1] && a->w_a[2] && a->b_a[0] && a->b_a[1] && a->b_a[2] && a->b_a[3] && a->w_a4m && a->w_a4s && a->b_a4,
                "bd_imagine_cat_forward: missing weights");
-    BD_REQUIRE(a->start_feat && a->eps_action && a->eps_entropy && a->q_prior, "bd_imagine_cat_forward: missing inputs");
+    BD_REQUIRE(a->start_feat && a->eps_action && a->q_prior && (a->eps_entropy || a->sv_act_stats),
+               "bd_imagine_cat_forward: missing inputs");
     BD_REQUIRE(a->feat && a->sidx && a->prior_logits && a->entropy && a->action, "bd_imagine_cat_forward: missing outputs");
     const int Kb_h = cdiv(a->Be, 16), Kb_a = cdiv(a->A, 16), Kb_hd = cdiv(a->Hd, 16);
     const int wmax = a->Be > a->Hd ? a->Be : a->Hd;
@@ -929,7 +930,7 @@ int bd_imagine_cat_forward(const bd_imagine_cat_fwd_args* a, void* stream) {
     if (lds > 64 * 1024 && allow_big_lds(imagine_cat_fwd_kernel)) return -1;
     hipLaunchKernelGGL(imagine_cat_fwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);
     BD_CHECK_LAUNCH("bd_imagine_cat_forward");
-    if (a->sv_act_stats != nullptr)     // the entropy estimate is off the recurrence (imagine.hip)
+    if (a->sv_act_stats != nullptr && a->eps_entropy != nullptr)     // the entropy estimate is off the recurrence (imagine.hip)
         return bd_actor_entropy(a->eps_entropy, a->sv_act_stats, a->entropy, a->Hm, a->N, a->A, a->n_samples, stream);
     return 0;
 }

@@ -328,6 +328,12 @@ class DreamerEngine:
             torch.cuda.set_stream(self._main_stream)
         self._pending_opt: List[tuple] = []
         self._opt_over: Dict[str, dict] = {}
+        # perf-mode noise: Philox keyed by the process seed (torch.manual_seed before building the agent, src/main.py:56-58)
+        # and the rank, counter = step index per phase
+        # (read at the FIRST perf-mode draw, so that seeding torch any time before training reproduces the run)
+        self._rng_seed: Optional[int] = None
+        self._rng_step = {"wm": 0, "bh": 0}
+        self._rng_entropy_step = 0
         self._log_ring: List[_LogRecord] = []
         self._log_i = 0
         self._cur_rec: Optional[_LogRecord] = None
@@ -846,7 +852,7 @@ class DreamerEngine:
             a.b_a[l] = ptr(ac(f"model.{2 * l}.bias"))
         a.w_a4m, a.w_a4s, a.b_a4 = ptr(pk["a4m"]), ptr(pk["a4s"]), ptr(ac(f"model.{2 * DENSE_LAYERS}.bias"))
         a.start_feat, a.start_sidx = ptr(start_feat), ptr(start_sidx)
-        a.eps_action, a.eps_entropy, a.q_prior = ptr(noise["action"]), ptr(noise["entropy"]), ptr(noise["img_prior"])
+        a.eps_action, a.eps_entropy, a.q_prior = ptr(noise["action"]), ptr(noise.get("entropy")), ptr(noise["img_prior"])
         a.act_raw_init_std, a.act_min_std, a.act_mean_scale = ACT_RAW_INIT_STD, ACT_MIN_STD, ACT_MEAN_SCALE
         ifeat = self.buf(tag + feat_tag + "ifeat", Mi, d.Be + d.S)
         a.feat = ptr(ifeat)
@@ -861,6 +867,8 @@ class DreamerEngine:
             a.sv_p = ptr(self.buf("isv_p", Mi, d.Hd))
         with self.span("imagine_fwd"):
             cabi.check(lib.bd_imagine_cat_forward(C.byref(a), cabi.stream()))
+        if save and noise.get("entropy") is None:       # perf mode: the scan alone ran; the estimator draws in-kernel
+            self._entropy_estimate(noise, ent, Hm, N)
         self._img_split_rows = 0
         return ifeat, ent, act
 
@@ -903,8 +911,8 @@ class DreamerEngine:
                 cabi.check(lib.bd_categorical_head_forward(ptr(out), ptr(eps), M, d.cat_D, d.cat_C, ptr(pst), ptr(probs),
                                                            cabi.stream()))
             return pst, out, out
-        pm, ps, pst = (self.buf(tag + "prior_mean", M, d.S), self.buf(tag + "prior_std", M, d.S),
-                       self.buf(tag + "prior_state", M, d.S))
+        pm, ps = self.buf(tag + "prior_mean", M, d.S), self.buf(tag + "prior_std", M, d.S)
+        pst = self.buf(tag + "prior_state", M, d.S) if eps is not None else None     # (perf mode: the unused sample is not drawn)
         cabi.check(lib.bd_gauss_head_forward(ptr(out), ptr(eps), M, d.S, self.hp["min_std_dev"], ptr(pm), ptr(ps),
                                              ptr(pst), cabi.stream()))
         return pst, pm, ps
@@ -964,7 +972,7 @@ class DreamerEngine:
             a.b_a[l] = ptr(ac(f"model.{2 * l}.bias"))
         a.w_a4m, a.w_a4s, a.b_a4 = ptr(pk["a4m"]), ptr(pk["a4s"]), ptr(ac(f"model.{2 * DENSE_LAYERS}.bias"))
         a.start_feat = ptr(start_feat)
-        a.eps_action, a.eps_entropy, a.eps_prior = ptr(noise["action"]), ptr(noise["entropy"]), ptr(noise["img_prior"])
+        a.eps_action, a.eps_entropy, a.eps_prior = ptr(noise["action"]), ptr(noise.get("entropy")), ptr(noise["img_prior"])
         a.min_std, a.act_raw_init_std = self.hp["min_std_dev"], ACT_RAW_INIT_STD
         a.act_min_std, a.act_mean_scale = ACT_MIN_STD, ACT_MEAN_SCALE
         ifeat = self.buf(tag + feat_tag + "ifeat", Mi, d.Be + d.S)
@@ -995,7 +1003,8 @@ class DreamerEngine:
                 a.Hm = Hm - H1
                 a.start_feat = ptr(ifeat) + (r0 - N) * (d.Be + d.S) * f4
                 a.eps_action = ptr(noise["action"]) + r0 * d.A * f4
-                a.eps_entropy = ptr(noise["entropy"]) + r0 * d.n_entropy * d.A * f4
+                if noise.get("entropy") is not None:
+                    a.eps_entropy = ptr(noise["entropy"]) + r0 * d.n_entropy * d.A * f4
                 a.eps_prior = ptr(noise["img_prior"]) + r0 * d.S * f4
                 a.feat = ptr(ifeat) + r0 * (d.Be + d.S) * f4
                 a.prior_mean = a.prior_mean + r0 * d.S * f4
@@ -1008,10 +1017,20 @@ class DreamerEngine:
                     a.sv_p = a.sv_p + r0 * d.Hd * f4
                 cabi.check(lib.bd_imagine_forward_scan(C.byref(a), cabi.stream()))
         if save:        # the entropy estimate of all Hm x N rows: off the recurrence (bd_actor_entropy), outside the scan's span
-            cabi.check(lib.bd_actor_entropy(ptr(noise["entropy"]), ptr(self._buf["sv_act_stats"]), ptr(ent), Hm, N, d.A,
-                                            d.n_entropy, cabi.stream()))
+            self._entropy_estimate(noise, ent, Hm, N)
         self._img_split_rows = H1 * N
         return ifeat, ent, act
+
+    def _entropy_estimate(self, noise, ent: torch.Tensor, Hm: int, N: int) -> None:
+        """SampleDist.entropy of every imagined action (src/models.py:725-733) from the (mean, std) the scan left in
+        sv_act_stats; explicit draws (parity) or, perf mode (noise["entropy"] is None), draws generated in the kernel."""
+        d = self.d
+        if noise.get("entropy") is not None:
+            cabi.check(lib.bd_actor_entropy(ptr(noise["entropy"]), ptr(self._buf["sv_act_stats"]), ptr(ent), Hm, N, d.A,
+                                            d.n_entropy, cabi.stream()))
+        else:
+            cabi.check(lib.bd_actor_entropy_rng(self.rng_seed, self._rng_entropy_step, self.RNG_STREAMS["entropy"],
+                                                ptr(self._buf["sv_act_stats"]), ptr(ent), Hm, N, d.A, d.n_entropy, cabi.stream()))
 
     # ------------------------------------------------------------------------------------------ train step
     def plan(self, belief: torch.Tensor, state: torch.Tensor, horizon: int, iters: int, candidates: int, top: int,
@@ -1069,21 +1088,51 @@ class DreamerEngine:
                                         ptr(std), st))
         return mean
 
+    @property
+    def rng_seed(self) -> int:
+        if self._rng_seed is None:
+            self.set_noise_seed(int(torch.initial_seed()))
+        return self._rng_seed
+
+    def set_noise_seed(self, seed: int) -> None:
+        """Key of the perf-mode noise generator (default: torch.initial_seed() at the first draw); ranks get distinct keys."""
+        self._rng_seed = (int(seed) + 0x9E3779B97F4A7C15 * (self.dp.rank + 1)) & 0xFFFFFFFFFFFFFFFF
+        self._rng_step = {"wm": 0, "bh": 0}
+
+    # noise streams of the perf-mode generator (csrc/bd_rng.h: counter = (index, stream id, step))
+    RNG_STREAMS = {"obs_post": 1, "action": 2, "img_prior": 3, "entropy": 4, "obs_prior": 5}
+
     def make_noise(self, B: int, part: str = "all") -> Dict[str, torch.Tensor]:
-        """On-device standard-normal noise for one step (perf mode; parity tests pass explicit arrays), drawn on the
-        current stream.  part: "wm" (observe scan), "bh" (imagination) or "all"."""
+        """Noise of one step in perf mode (parity tests pass explicit arrays): ONE bd_rng_fill launch per phase on the
+        current stream -- Philox4x32-10, counter-based, keyed by the process seed and the step index, so a run is
+        reproducible whatever the stream timing.  part: "wm" (observe scan), "bh" (imagination) or "all".
+        Not drawn at all: the prior-state sample of the observe step (src/models.py:256 draws it, nothing on the training
+        path reads it) and the 100-sample entropy draws -- bd_actor_entropy_rng generates those inside the estimator
+        ("entropy": None), 13.7 MB per step at configs[1] that never exist in HBM."""
         d = self.d
         T, N, Hm = d.T, d.T * B, d.Hm
         shapes = {}
         if part in ("all", "wm"):
-            shapes.update(obs_prior=(T, B, d.S), obs_post=(T, B, d.S))
+            shapes.update(obs_post=(T, B, d.S))
         if part in ("all", "bh"):
-            shapes.update(action=(Hm, N, d.A), entropy=(Hm, d.n_entropy, N, d.A), img_prior=(Hm, N, d.S))
-        if d.categorical:       # the state draws are the sampler's Exp(1) variates, one per class (torch.multinomial)
-            shapes.pop("obs_prior", None)       # the prior sample is not on the training path
-            return {k: (self.buf("noise_" + k, *s).exponential_() if k in ("obs_post", "img_prior")
-                        else self.buf("noise_" + k, *s).normal_()) for k, s in shapes.items()}
-        return {k: self.buf("noise_" + k, *s).normal_() for k, s in shapes.items()}
+            shapes.update(action=(Hm, N, d.A), img_prior=(Hm, N, d.S))
+        exp_kind = ("obs_post", "img_prior") if d.categorical else ()       # the sampler's Exp(1) variates, one per class
+        out: Dict[str, Optional[torch.Tensor]] = {}
+        a = cabi.RngFillArgs()
+        a.n, a.seed, a.step = len(shapes), self.rng_seed, self._rng_step[part if part != "all" else "wm"]
+        for i, (k, shp) in enumerate(shapes.items()):
+            t = out[k] = self.buf("noise_" + k, *shp)
+            a.t[i] = cabi.RngTensor(t.data_ptr(), t.numel(), cabi.BD_RNG_EXPONENTIAL if k in exp_kind else cabi.BD_RNG_NORMAL,
+                                    self.RNG_STREAMS[k])
+        cabi.check(lib.bd_rng_fill(C.byref(a), cabi.stream()))
+        if part in ("all", "wm"):
+            out["obs_prior"] = None
+            self._rng_step["wm"] += 1
+        if part in ("all", "bh"):
+            out["entropy"] = None
+            self._rng_entropy_step = self._rng_step["bh"]
+            self._rng_step["bh"] += 1
+        return out
 
     def _optimizer_step_or_defer(self, span: str, group: str, slot: int, lr: float, red_ws: torch.Tensor) -> None:
         """Actor / critic optimiser step of the behaviour phase.  Data-parallel + pipelined: queued and issued by the NEXT
@@ -1222,7 +1271,7 @@ class DreamerEngine:
                                     feat_tag=feat_tag)
         cat = d.categorical
         with self.span("wm_heads_fwd"):
-            _, pm, ps = self.prior_head(feat, N, None if cat else noise["obs_prior"])
+            _, pm, ps = self.prior_head(feat, N, None if cat else noise.get("obs_prior"))
             if self.pixel:
                 om_out, om_acts, om_layers = self.conv.decode(feat).view(N, d.O), None, None
                 obs_t = self.conv.acts_enc[0].view(N, d.O)      # the same images in the NHWC order of the prediction

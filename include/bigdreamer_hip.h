@@ -350,6 +350,34 @@ int bd_lambda_return_forward(const float* reward, const float* value, int Hm, in
 int bd_lambda_return_backward(const float* dreturns, float dret_const, int Hm, int N, float discount,
                               float lambda_, float* dreward, float* dvalue, void* stream);
 
+/* ---- perf-mode noise: Philox4x32-10, counter-based (csrc/bd_rng.h).  key = seed, counter = (index of a group of four
+ * values, stream id, step): any element of any stream of any step is computable on its own.  The parity path never uses
+ * this: tests pass the reference's draws as explicit arrays.
+ * bd_rng_fill: up to BD_RNG_MAX_TENSORS noise tensors in ONE launch (standard normals: src/models.py:72 randn_like,
+ * src/dreamer.py:443 rsample; Exp(1): the variates torch.multinomial's single-draw path consumes, src/models.py:114-115). */
+#define BD_RNG_MAX_TENSORS 6
+#define BD_RNG_NORMAL 0
+#define BD_RNG_EXPONENTIAL 1
+typedef struct {
+    int n;
+    unsigned long long seed;
+    unsigned long long step;
+    struct {
+        float* p;
+        size_t count;
+        int kind;                 /* BD_RNG_NORMAL | BD_RNG_EXPONENTIAL */
+        unsigned stream_id;       /* distinct per tensor */
+    } t[BD_RNG_MAX_TENSORS];
+} bd_rng_fill_args;
+int bd_rng_fill(const bd_rng_fill_args* a, void* stream);
+/* The generator's core on the host: out4 = Philox4x32-10(counter ctr4, key key2) (known-answer tests, no GPU needed). */
+int bd_philox4x32_10(const unsigned* ctr4, const unsigned* key2, unsigned* out4);
+/* bd_actor_entropy with the n_samples draws per (row, action dim) generated IN the kernel (stream `stream_id` of `seed`,
+ * `step`): the (Hm x n_samples x N x A) entropy noise tensor -- 13.7 MB per step at configs[1], 233 MB at A = 17 -- is never
+ * written to or read from HBM.  Same estimator, same outputs as bd_actor_entropy (SampleDist.entropy, src/models.py:725-733). */
+int bd_actor_entropy_rng(unsigned long long seed, unsigned long long step, unsigned stream_id, float* act_stats,
+                         float* entropy, int Hm, int N, int A, int n_samples, void* stream);
+
 /* ---- plain GEMM  C[M x N] (+)= A[M x K] B[N x K]^T  (csrc/gemm.hip; fp32 MFMA, exact fp32 products and sums).
  * The pixel decoder's one plain GEMM: the dgrad of ConvTranspose2d(E -> 128, k5, s2) on a 1 x 1 map
  * (src/models.py:338-341), d l0[M x E] = g[M x 3200] W[E x 3200]^T.  Any K / leading dimensions / alignment (16-byte
@@ -472,6 +500,8 @@ typedef struct {
     float* sv_actor; float* sv_act_stats; float* sv_x; float* sv_gates; float* sv_p;   /* or NULL            */
 } bd_imagine_cat_fwd_args;
 int bd_imagine_cat_forward(const bd_imagine_cat_fwd_args* a, void* stream);
+/* (eps_entropy == NULL with sv_act_stats != NULL: the scan alone -- the caller runs the entropy estimate itself,
+ * bd_actor_entropy or bd_actor_entropy_rng on sv_act_stats, as after bd_imagine_forward_scan) */
 
 typedef struct {
     int N, Hm, Be, D, C, A, Hd;
