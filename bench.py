@@ -279,10 +279,10 @@ def surface_ms_per_step(d, dev, steps, warmup, bursts_of=(5, 50)):
 
 
 def child_json(extra_args, timeout=600):
-    """Run this script again as a CHILD process (fresh HIP context and streams) and return the JSON object it prints.
-    A second engine built in a process that has already run one is measured 10-15 % slow (3.65 against 3.2 ms/step for
-    the surface leg, 16.0 against 15.7 for the pixel leg): the legs of the default run are therefore separate processes,
-    one after the other, while this one holds no engine."""
+    """Run this script again as a CHILD process (fresh HIP context) and return the JSON object it prints: the legs of the
+    default run are separate processes, one after the other, while this one holds no engine.  (Round 2 needed this because
+    a second engine in one process ran 10-15 % slow; the cause -- its pool streams landing on shared hardware queues -- is
+    fixed in engine._engine_stream and tested, the isolation stays because it also keeps the legs' allocator states apart.)"""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__)] + list(extra_args)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}

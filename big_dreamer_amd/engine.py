@@ -240,6 +240,26 @@ class WgradBatch:
         self.items = []
 
 
+# Pipeline streams are per PROCESS and device, not per engine.  torch hands out streams from a fixed pool and HIP maps them
+# onto a handful of hardware queues in creation order: a second engine built in the same process (Planet then Dreamer, an
+# evaluation agent beside a training agent, the legs of a benchmark) used to get the NEXT pool streams, whose queue
+# assignment made two of its three hot streams share a hardware queue -- the same kernels ran 10-15 % slower (round 2:
+# "cause not found").  Engines now share one stream per (device, role, priority); engines used alternately are merely
+# ordered against each other on them, which is what a single-threaded caller does anyway.  BD_SHARE_STREAMS=0: one set per
+# engine (diagnosis).
+_STREAM_CACHE: Dict[tuple, "torch.cuda.Stream"] = {}
+
+
+def _engine_stream(dev: torch.device, role: str, priority: int) -> "torch.cuda.Stream":
+    if os.environ.get("BD_SHARE_STREAMS", "1") == "0":
+        return torch.cuda.Stream(device=dev, priority=priority)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), role, priority)
+    st = _STREAM_CACHE.get(key)
+    if st is None:
+        st = _STREAM_CACHE[key] = torch.cuda.Stream(device=dev, priority=priority)
+    return st
+
+
 class DreamerEngine:
     def __init__(self, dims: Dims, hp: Optional[dict] = None, device="cuda", params: Optional[dict] = None,
                  world_size: int = 1, process_group=None, phase_groups: Optional[dict] = None):
@@ -285,12 +305,12 @@ class DreamerEngine:
         # head-chain and wgrad kernels already fill the chip and slow imagine_bwd down by contention), so it is off
         # by default (BD_OVERLAP_CRITIC=1 enables it; parity-tested either way).
         self.overlap_critic = os.environ.get("BD_OVERLAP_CRITIC", "0") == "1"
-        self._side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("BD_SIDE_PRIO", "0")))
-        self._s_heads = torch.cuda.Stream(device=self.dev, priority=-1)     # heads of the first half of a split rollout
+        self._side = _engine_stream(self.dev, "side", int(os.environ.get("BD_SIDE_PRIO", "0")))
+        self._s_heads = _engine_stream(self.dev, "heads", -1)     # heads of the first half of a split rollout
         self.img_split = os.environ.get("BD_IMG_SPLIT", "0") == "1"
         self._img_split_rows = 0
         # pixel mode: decoder weight gradients under the observe scan
-        self._s_early = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("BD_EARLY_PRIO", "0")))
+        self._s_early = _engine_stream(self.dev, "early", int(os.environ.get("BD_EARLY_PRIO", "0")))
         # Cross-step software pipeline (on unless BD_PIPELINE=0).  Dynamics learning of step k+1 reads only the world
         # model that step k's model optimiser wrote, never what step k's behaviour learning (imagination, actor,
         # critic) produces, while behaviour learning k needs the world model k and the posteriors k.  So the two
@@ -305,11 +325,11 @@ class DreamerEngine:
         # `feat` (posterior features, read by behaviour learning), the imagined features and the lambda-returns (read by
         # the critic update) are double-buffered by step parity.
         self.pipeline = os.environ.get("BD_PIPELINE", "1") != "0"
-        self._s_wm = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("BD_WM_PRIO", "-1")))   # the scan is latency-bound: dispatch it first
+        self._s_wm = _engine_stream(self.dev, "wm", int(os.environ.get("BD_WM_PRIO", "-1")))   # the scan is latency-bound: dispatch it first
         # state observations: the actor chain bounds the step; pixels: the conv-heavy dynamics chain does, and behaviour
         # learning should only fill its gaps (BD_BH_PRIO overrides: -1 high, 0 normal)
         bh_prio = int(os.environ.get("BD_BH_PRIO", "0" if self.pixel else "-1"))
-        self._s_bh = torch.cuda.Stream(device=self.dev, priority=bh_prio)      # critic: _side
+        self._s_bh = _engine_stream(self.dev, "bh", bh_prio)      # critic: _side
         self._ev_bh_wm_free: Optional[torch.cuda.Event] = None
         self._ev_bh_done: List[Optional[torch.cuda.Event]] = [None, None]
         self._ev_cr_done: List[Optional[torch.cuda.Event]] = [None, None]
@@ -324,7 +344,7 @@ class DreamerEngine:
             # stream waits for the communicator to drain, i.e. for behaviour learning of the previous step -- the
             # cross-step pipeline collapses to the serial schedule (measured with a one-rank communicator: 3.47 ->
             # 5.33 ms/step).  Data-parallel runs therefore move the calling thread to a non-blocking stream.
-            self._main_stream = torch.cuda.Stream(self.dev)
+            self._main_stream = _engine_stream(self.dev, "main", 0)
             torch.cuda.set_stream(self._main_stream)
         self._pending_opt: List[tuple] = []
         self._opt_over: Dict[str, dict] = {}
