@@ -158,20 +158,38 @@ __global__ __launch_bounds__(kThreads) void wgrad_grouped_kernel(const bd_wgrad_
 // disjoint banks); the next stage's global loads fly under this stage's MFMAs; one barrier per stage.
 constexpr int kWB = 13;               // 16-blocks per workgroup tile edge
 constexpr int kWBK = 12;              // ... along K when K needs several tiles: 3 blocks per wave column, no padded MFMAs
-__host__ __device__ __forceinline__ int wgrad_tiles_k(int KB) { return KB <= kWB ? 1 : cdiv(KB, kWBK); }
+constexpr int kWBKDeep = 36;          // ... of a NARROW tile (<= 4 dpre blocks: conv layers with <= 64 channels): 9 blocks per wave column
+// A narrow tile keeps few accumulators per wave (2 x 3 at 12 K blocks): 48 MFMAs per wave and 32-row stage against ~2.5k
+// cycles of per-stage DMA issue / wait / barrier, and its 64-wide dpre operand was re-read once per 12-block K tile (6 x for
+// the 1152-wide decoder layer: 2.9 x the algorithmic bytes, round-2 PMC).  Deep K tiles (up to 36 blocks: 2 x 9
+// accumulators per wave) triple the MFMAs per staged row and cut the re-reads to 2 x.
+__host__ __device__ __forceinline__ int wgrad_tiles_k(int NB, int KB, bool deep_ok) {
+    if (KB <= kWB) return 1;
+    return (NB <= 4 && deep_ok) ? cdiv(KB, kWBKDeep) : cdiv(KB, kWBK);
+}
+// the act operand of this GEMM takes the 16-byte LDS-DMA form (what the deep tiles are built for)
+__host__ inline bool wgrad_act16(const bd_wgrad_desc& d) {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if ((d.K & 3) != 0 || !al16(d.act1)) return false;
+    if (d.g_nseg > 0) return (d.g_C & 3) == 0 && (d.g_seglen & 3) == 0;
+    return (d.lda1 & 3) == 0 && (d.M1 == d.M || ((d.lda2 & 3) == 0 && al16(d.act2)));
+}
 constexpr int kWLd = 240;             // LDS row stride in floats: 14 blocks + pad, == 16 mod 32
 constexpr int kWRows = 16;            // rows per stage
 constexpr int kWStage = 2 * kWRows * kWLd;   // floats per stage: dpre rows | act rows
 constexpr int kWRing = 3;             // stage buffers (DMA runs two stages ahead)
 constexpr int kWRowsTall = 32;         // rows per stage of a narrow tile (<= 64 dpre columns): half the stage overhead per row
 constexpr int kWLdNarrow = 80;         // its dpre row stride: 64 + 16, == 16 mod 32
-constexpr size_t kWideLdsBytes = (size_t)kWRing * kWRowsTall * (kWLdNarrow + kWLd) * sizeof(float);   // 122 880 (>= 3 x 30 720)
+constexpr int kWLdDeep = 592;          // act row stride of a deep narrow tile: 36 blocks + pad, == 16 mod 32
+constexpr size_t kWideLdsBytes = 147456;   // >= 3 x 16 x (80 + 592) x 4 = 129 024 (deep), 3 x 32 x 320 x 4 = 122 880 (tall narrow),
+                                           //    8 waves x 2 x (1280 + 1024) x 4 = 147 456 (thin-image bodies)
+static_assert((size_t)kWRing * kWRows * (kWLdNarrow + kWLdDeep) * sizeof(float) <= kWideLdsBytes, "deep stage ring");
 constexpr int kWThreads = 512;        // 8 waves: 2 per SIMD, so LDS latency and the stage barrier hide under the other wave
 
 // WN x WK = 16-blocks per wave (the 2 x 4 waves cover up to 2WN x 4WK blocks).  The MFMA loop is branch-free: a wave
 // whose share is smaller multiplies zero-filled LDS columns (the workgroup runs at the pace of its fullest wave
 // anyway); only the stores are guarded.
-template <int WN, int WK, int ROWS = kWRows, int PLD = kWLd>
+template <int WN, int WK, int ROWS = kWRows, int PLD = kWLd, int ALD = kWLd>
 __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* __restrict__ ws, float* wlds, int hb, int Kext,
                                                 int z, int n0, int k0, int nb_cnt, int kb_cnt) {
     const int m_begin = z * d.rows_per;
@@ -186,7 +204,7 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
     const int kq = kb_cnt >> 2, krem = kb_cnt & 3;
     const int my_kb0 = wc * kq + min(wc, krem), my_kb = kq + (wc < krem ? 1 : 0);
 
-    constexpr int kStage = ROWS * (PLD + kWLd);     // floats per stage: ROWS dpre rows (stride PLD) | ROWS act rows (stride kWLd)
+    constexpr int kStage = ROWS * (PLD + ALD);      // floats per stage: ROWS dpre rows (stride PLD) | ROWS act rows (stride ALD)
     constexpr int kRpw = ROWS / 8;                  // rows per wave and stage
     static_assert(kWRing * kStage * sizeof(float) <= kWideLdsBytes, "stage ring exceeds the LDS request");
     floatx4 acc[WN][WK];
@@ -206,7 +224,7 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
     for (int i = threadIdx.x; i < kWRing * kStage; i += kWThreads) wlds[i] = 0.f;
     __syncthreads();
     if (hb && d.K >= k0 && d.K < k0 + kb_cnt * 16 && threadIdx.x < kWRing * ROWS)
-        wlds[(threadIdx.x / ROWS) * kStage + ROWS * PLD + (threadIdx.x % ROWS) * kWLd + (d.K - k0)] = 1.f;
+        wlds[(threadIdx.x / ROWS) * kStage + ROWS * PLD + (threadIdx.x % ROWS) * ALD + (d.K - k0)] = 1.f;
     // 16-byte LDS-DMA (one 1 KiB wave-instruction per operand row) wherever rows and columns allow it: the dword form
     // moves 256 B per instruction and ran the whole kernel at ~1.2 TB/s of operand traffic, not at its MFMA rate.
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -216,11 +234,17 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
                     (gathered ? ((d.g_C & 3) == 0 && (d.g_seglen & 3) == 0 && al16(d.act1))
                               : ((d.lda1 & 3) == 0 && al16(d.act1) && (d.M1 == d.M || ((d.lda2 & 3) == 0 && al16(d.act2)))));
     // gathered operand: the window offset of this lane's columns does not depend on the row -- once per workgroup
-    int goff[4] = {0, 0, 0, 0};
+    // (16-byte form: chunk cc = the 256 floats 4 * lane + 256 * cc; dword form: the 64 floats lane + 64 * cc)
+    constexpr int kCh4 = (ALD + 255) / 256;         // 16-byte chunks per act row (1 for the 13-block tiles, 3 for deep ones)
+    constexpr int kCh1 = (ALD + 63) / 64;           // dword chunks per act row
+    constexpr int kGo = kCh1;
+    int goff[kGo];
+#pragma unroll
+    for (int cc = 0; cc < kGo; ++cc) goff[cc] = 0;
     if (gathered) {
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const int k = k0 + (a4 ? 4 * lane : lane + 64 * cc), sgm = k / d.g_seglen;
+        for (int cc = 0; cc < kGo; ++cc) {
+            const int k = k0 + (a4 ? 4 * lane + 256 * cc : lane + 64 * cc), sgm = k / d.g_seglen;
             goff[cc] = sgm * d.g_IW * d.g_C + (k - sgm * d.g_seglen);
         }
     }
@@ -229,7 +253,7 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
         for (int rr = 0; rr < kRpw; ++rr) {
             const int m = m0 + wave * kRpw + rr;                   // wave-uniform
             float* P = buf + (wave * kRpw + rr) * PLD;
-            float* A = buf + ROWS * PLD + (wave * kRpw + rr) * kWLd;
+            float* A = buf + ROWS * PLD + (wave * kRpw + rr) * ALD;
             if (m < m_end) {
                 const float* prow = d.dpre + (size_t)m * d.ldp + n0;
                 if (p4) {
@@ -250,11 +274,14 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
                     abase = (m < d.M1 ? d.act1 + (size_t)m * d.lda1 : d.act2 + (size_t)(m - d.M1) * d.lda2) + k0;
                 }
                 if (a4) {
-                    if (4 * lane < kcol)
-                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(abase + (gathered ? goff[0] : 4 * lane)), (lds_ptr_t)A, 16, 0, 0);
+#pragma unroll
+                    for (int cc = 0; cc < kCh4; ++cc)
+                        if (4 * lane + 256 * cc < kcol)
+                            __builtin_amdgcn_global_load_lds((glb_ptr_t)(abase + (gathered ? goff[cc] : 4 * lane + 256 * cc)),
+                                                             (lds_ptr_t)(A + 256 * cc), 16, 0, 0);
                 } else {
 #pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
+                    for (int cc = 0; cc < kCh1; ++cc) {
                         const int c = lane + 64 * cc;
                         if (c < kcol)
                             __builtin_amdgcn_global_load_lds((glb_ptr_t)(abase + (gathered ? goff[cc] : c)), (lds_ptr_t)(A + 64 * cc), 4,
@@ -263,10 +290,10 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
                 }
             } else {
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
+                for (int cc = 0; cc < kCh1; ++cc) {
                     const int c = lane + 64 * cc;
                     if (c < PLD) P[c] = 0.f;
-                    if (c < kWLd) A[c] = 0.f;
+                    if (c < ALD) A[c] = 0.f;
                 }
             }
         }
@@ -276,7 +303,7 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
     // waits for stage st+1 (`vmcnt(n)` with n = this wave's DMA instructions per stage leaves the newest stage in
     // flight; vmcnt retires in order).  A narrow tile (N = 32 / 64: conv layers) has ~1.5k cycles of MFMAs per
     // 16-row stage against >= 2.5k cycles of loaded DMA latency: with two buffers every stage waited for its fetch.
-    const int n_dma = kRpw * ((p4 ? 1 : cdiv(ncol, 64)) + (a4 ? 1 : cdiv(kcol, 64)));    // 4, 6, ..., 16 per wave and full stage
+    const int n_dma = kRpw * ((p4 ? 1 : cdiv(ncol, 64)) + (a4 ? cdiv(kcol, 256) : cdiv(kcol, 64)));    // 4, 6, ..., 16 per wave and full stage
     auto wait_keep_newest = [&]() {
         switch (n_dma) {
             case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
@@ -303,14 +330,14 @@ __device__ __forceinline__ void wgrad_wide_body(const bd_wgrad_desc& d, float* _
         if (more) issue(wlds + ((st + 2) % kWRing) * kStage, m_begin + (st + 2) * ROWS);
         BD_DSTAMP(sb, 1);
         const float* Pb = buf + lrow * PLD + my_nb0 * 16 + lcol;
-        const float* Ab = buf + ROWS * PLD + lrow * kWLd + my_kb0 * 16 + lcol;
+        const float* Ab = buf + ROWS * PLD + lrow * ALD + my_kb0 * 16 + lcol;
 #pragma unroll
         for (int sl = 0; sl < ROWS / 4; ++sl) {
             float a[WN], b[WK];
 #pragma unroll
             for (int i = 0; i < WN; ++i) a[i] = Pb[sl * 4 * PLD + i * 16];
 #pragma unroll
-            for (int j = 0; j < WK; ++j) b[j] = Ab[sl * 4 * kWLd + j * 16];
+            for (int j = 0; j < WK; ++j) b[j] = Ab[sl * 4 * ALD + j * 16];
 #pragma unroll
             for (int i = 0; i < WN; ++i)
 #pragma unroll
@@ -451,6 +478,153 @@ __device__ __forceinline__ void wgrad_dense_body(const bd_wgrad_desc& d, float* 
     }
 }
 
+// ---- thin-image conv weight gradients: the two layers that touch the 3-channel 64 x 64 image -----------------------------
+// Conv2d(3 -> 32, k4) (dpre = gradient of its output, 31 x 31 grid) and ConvTranspose2d(32 -> 3, k6) (dpre = its input, 30 x 30
+// grid): N = 32, K = 48 / 108, M = 2.2-2.4 MILLION rows -- 0.05 ms of MFMA work and 0.4 GB of operands each, which the
+// staged-row bodies above turned into 1.1-1.2 ms (tools/conv_probe.py: a 32-row stage moves two 64-192-byte DMA pieces per
+// row and pays a workgroup barrier for 48 MFMAs per wave).  Here every WAVE is its own pipeline: it owns the grid rows
+// it = wave, wave + 8, ... of the workgroup's images, and for a grid row it DMAs the two CONTIGUOUS pieces it needs -- the
+// band of k image rows under that grid row (k x 768 B) and the row's dpre values (gw x 128 B) -- into its private,
+// double-buffered LDS region (1 KiB wave-instructions, fragment-agnostic), then forms both MFMA operands with ds_read_b32:
+//   A (dpre):  lane (n = l & 15, q = l >> 4)  ->  dpre[x = 4 s + q][16 nb + n]
+//   B (window): lane (j = l & 15, q)          ->  band[ky][(2 x + kx) C + c]   with (ky, kx, c) of k index 16 kb + j
+// No workgroup barrier until the final cross-wave sum; the bias gradient is a VALU column sum of the A values.
+// Pixels x >= gw of the last slice multiply zero dpre rows (the region's tail is zero-filled once and never written).
+constexpr int kThinMaxKB = 7;                 // K <= 112
+constexpr int kThinDpreFloats = 1024;         // gw <= 32 pixels x 32 channels
+__host__ __device__ inline int thin_band_floats(int k, int roww) { return (k * roww + 64 + 255) & ~255; }
+__host__ inline bool wgrad_thin_ok(const bd_wgrad_desc& d) {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (d.g_nseg <= 0 || d.g_C > 4 || d.N != 32 || d.ldp != 32 || d.g_gw > 32) return false;
+    if (cdiv(d.K, 16) > kThinMaxKB || d.g_seglen != d.g_nseg * d.g_C) return false;
+    const int roww = d.g_IW * d.g_C;
+    if ((roww & 3) != 0 || !al16(d.act1) || !al16(d.dpre)) return false;
+    // 8 waves x 2 buffers x (band + dpre row) must fit the kernel's LDS request, and the final partials too
+    const size_t per_wave = 2 * (size_t)(thin_band_floats(d.g_nseg, roww) + kThinDpreFloats) * sizeof(float);
+    return 8 * per_wave <= kWideLdsBytes && (size_t)8 * 2 * kThinMaxKB * 1024 <= kWideLdsBytes;
+}
+
+template <int KB>
+__device__ __forceinline__ void wgrad_thin_body(const bd_wgrad_desc& d, float* __restrict__ ws, float* wlds, int z) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hb = d.db != nullptr;
+    const int Kext = d.K + hb;
+    const int gh = d.g_gh, gw = d.g_gw, C = d.g_C, kk = d.g_nseg;
+    const int roww = d.g_IW * C, band = kk * roww, drow = gw * 32;
+    const int band_al = thin_band_floats(kk, roww);
+    const int per_buf = band_al + kThinDpreFloats;
+    float* mine = wlds + (size_t)wave * 2 * per_buf;
+    for (int i = lane; i < 2 * per_buf; i += 64) mine[i] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int imgs = d.M / (gh * gw), ipw = d.rows_per / (gh * gw);
+    const int img0 = z * ipw, img1 = min(imgs, img0 + ipw);
+    const int items = (img1 - img0) * gh;                       // (image, grid row) pairs of this workgroup
+    const int nband = cdiv(band, 256), ndrow = cdiv(drow, 256); // 1 KiB DMA pieces
+    auto issue = [&](int it, float* buf) {
+        const int img = img0 + it / gh, y = it - (it / gh) * gh;
+        const float* sb = d.act1 + ((size_t)img * d.g_IH + 2 * y) * roww;
+        const float* sd = d.dpre + ((size_t)img * gh + y) * gw * 32;
+        for (int ch = 0; ch < nband; ++ch)
+            if (4 * lane + 256 * ch < band)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(sb + 4 * lane + 256 * ch), (lds_ptr_t)(buf + 256 * ch), 16, 0, 0);
+        for (int ch = 0; ch < ndrow; ++ch)
+            if (4 * lane + 256 * ch < drow)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(sd + 4 * lane + 256 * ch), (lds_ptr_t)(buf + band_al + 256 * ch), 16, 0, 0);
+    };
+    const int n_dma = nband + ndrow;                            // per item and wave (7 or 9)
+    auto wait_keep_newest = [&]() {
+        switch (n_dma) {
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    // lane constants of the window operand: k index 16 kb + (lane & 15) -> (ky, kx, c) -> ky * roww + kx * C + c
+    int boff[KB];
+    bool bok[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int kidx = kb * 16 + (lane & 15);
+        bok[kb] = kidx < d.K;
+        const int ky = kidx / d.g_seglen;
+        boff[kb] = bok[kb] ? ky * roww + (kidx - ky * d.g_seglen) : 0;
+    }
+    floatx4 acc[2][KB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < KB; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float bsum[2] = {0.f, 0.f};
+    const int q = lane >> 4, n = lane & 15;
+    const int nsl = cdiv(gw, 4);
+    int it = wave, b = 0;
+    if (it < items) issue(it, mine);
+    for (; it < items; it += 8, b ^= 1) {
+        const bool more = it + 8 < items;
+        if (more) {
+            issue(it + 8, mine + (b ^ 1) * per_buf);
+            wait_keep_newest();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const float* Bd = mine + b * per_buf;
+        const float* Dp = Bd + band_al;
+        for (int sl = 0; sl < nsl; ++sl) {
+            const int x = 4 * sl + q;
+            const float a0 = Dp[x * 32 + n], a1 = Dp[x * 32 + 16 + n];
+            float bv[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) bv[kb] = bok[kb] ? Bd[boff[kb] + 2 * x * C] : 0.f;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                acc[0][kb] = mfma16(a0, bv[kb], acc[0][kb]);
+                acc[1][kb] = mfma16(a1, bv[kb], acc[1][kb]);
+            }
+            bsum[0] += a0;
+            bsum[1] += a1;
+        }
+        // this buffer is refilled by the DMA issued at the top of the NEXT iteration: its LDS reads must have returned
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // ---- cross-wave sum (fixed order) -> this split's slab ----
+    __syncthreads();
+    floatx4* R4 = reinterpret_cast<floatx4*>(wlds);
+    float* BS = wlds + (size_t)8 * 2 * KB * 256;                 // [8 waves][2][64]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j) R4[((wave * 2 + i) * KB + j) * 64 + lane] = acc[i][j];
+        BS[(wave * 2 + i) * 64 + lane] = bsum[i];
+    }
+    __syncthreads();
+    float* slab = ws + d.ws_off + (size_t)z * d.N * Kext;
+    for (int e = threadIdx.x; e < 2 * KB * 64; e += blockDim.x) {
+        const int blk = e >> 6, l = e & 63;
+        floatx4 s4 = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < 8; ++w) s4 += R4[(w * 2 * KB + blk) * 64 + l];
+        const int i = blk / KB, j = blk - i * KB;
+        const int k = j * 16 + (l & 15);
+        if (k < d.K) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(size_t)(i * 16 + 4 * (l >> 4) + r) * Kext + k] = s4[r];
+        }
+    }
+    if (hb && threadIdx.x < 32) {
+        const int i = threadIdx.x >> 4, nn = threadIdx.x & 15;
+        float t = 0.f;
+        for (int w = 0; w < 8; ++w)
+            for (int qq = 0; qq < 4; ++qq) t += BS[(w * 2 + i) * 64 + qq * 16 + nn];
+        slab[(size_t)(i * 16 + nn) * Kext + d.K] = t;
+    }
+}
+
 __global__ __launch_bounds__(kWThreads) void wgrad_wide_kernel(const bd_wgrad_desc* __restrict__ descs, int n,
                                                          float* __restrict__ ws) {
     extern __shared__ float wlds[];   // ring of kWRing stages: [ P: rows x stride | A: rows x kWLd ] (kWideLdsBytes)
@@ -467,6 +641,12 @@ __global__ __launch_bounds__(kWThreads) void wgrad_wide_kernel(const bd_wgrad_de
     const int tn = local / d.tiles_k, tk = local - tn * d.tiles_k;
     const int n0 = tn * nbw * 16, k0 = tk * kbw * 16;
     const int nb_cnt = min(nbw, NB - tn * nbw), kb_cnt = min(kbw, KB - tk * kbw);
+    if (d.g_pad == 1) {          // thin-image conv layer (bd_wgrad_plan: wgrad_thin_ok): wave-private row pipelines
+        const int kb_t = cdiv(d.K, 16);
+        if (kb_t <= 3) wgrad_thin_body<3>(d, ws, wlds, z);
+        else wgrad_thin_body<kThinMaxKB>(d, ws, wlds, z);
+        return;
+    }
     // The MFMA loop is branch-free over WN x WK blocks per wave, so the instantiation must fit the tile: a 4 x 12-block
     // tile (N = 64: conv layers) on the 7 x 4 body would issue 28 MFMAs per slice for 6 useful ones.
     const int hn = (nb_cnt + 1) >> 1, hk = (kb_cnt + 3) >> 2;      // blocks per wave row / wave column
@@ -512,6 +692,15 @@ __global__ __launch_bounds__(kWThreads) void wgrad_wide_kernel(const bd_wgrad_de
         else if (hk <= 3) BD_WN_BODY(WN, 3); \
         else BD_WN_BODY(WN, 4);            \
     } while (0)
+        if (hk > 4) {
+            // deep K tile (wgrad_tiles_k: up to 36 blocks, 9 per wave column): 16-row stages with a 592-float act row
+            // (37 blocks, == 16 mod 32); operands must take the 16-byte DMA form (conv layers with C % 4 == 0 do)
+#define BD_WDEEP(WN, WK) wgrad_wide_body<WN, WK, kWRows, kWLdNarrow, kWLdDeep>(d, ws, wlds, hb, Kext, z, n0, k0, nb_cnt, kb_cnt)
+            if (hn <= 1) { if (hk <= 8) BD_WDEEP(1, 8); else BD_WDEEP(1, 9); }
+            else { if (hk <= 8) BD_WDEEP(2, 8); else BD_WDEEP(2, 9); }
+#undef BD_WDEEP
+            return;
+        }
         if (hn <= 1) BD_WN_ROW(1);
         else BD_WN_ROW(2);
 #undef BD_WN_ROW
@@ -563,6 +752,10 @@ static bool wgrad_wide() {
     static const char* e = getenv("BD_WGRAD_WIDE");
     return !(e && e[0] == '0');
 }
+static bool thin_on() {        // BD_WGRAD_THIN=0: the staged-row bodies for the 3-channel layers too (A/B, tests)
+    static const char* e = getenv("BD_WGRAD_THIN");
+    return !(e && e[0] == '0');
+}
 static int wgrad_rows() {
     static const char* e = getenv("BD_WGRAD_ROWS");
     const int r = e ? atoi(e) : 0;
@@ -596,7 +789,7 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
         auto wgs = [&](int R) {
             long t = 0;
             for (int i = 0; i < n; ++i)
-                t += (long)cdiv(cdiv(descs[i].N, 16), kWB) * wgrad_tiles_k(cdiv(descs[i].K + (descs[i].db != nullptr), 16)) *
+                t += (long)cdiv(cdiv(descs[i].N, 16), kWB) * wgrad_tiles_k(cdiv(descs[i].N, 16), cdiv(descs[i].K + (descs[i].db != nullptr), 16), wgrad_act16(descs[i])) *
                      cdiv(descs[i].M > 0 ? descs[i].M : 1, R);
             return t;
         };
@@ -616,7 +809,7 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
     };
     auto desc_geo = [&](const bd_wgrad_desc& d, int* tiles, int* cost) {
         const int NB = cdiv(d.N, 16), KB = cdiv(d.K + (d.db != nullptr), 16);
-        const int tn = cdiv(NB, kWB), tk = wgrad_tiles_k(KB);
+        const int tn = cdiv(NB, kWB), tk = wgrad_tiles_k(NB, KB, wgrad_act16(d));
         *tiles = tn * tk;
         *cost = tile_cost(cdiv(NB, tn), cdiv(KB, tk));
     };
@@ -646,10 +839,19 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
                            (2 * (d.g_gw - 1)) * d.g_C + d.g_seglen <= d.g_IW * d.g_C,
                        "bd_wgrad_plan: descriptor %d has an inconsistent gather geometry", i);
         const int hb = d.db != nullptr;
-        if (wgrad_wide()) {
+        d.g_pad = 0;
+        if (wgrad_wide() && wgrad_thin_ok(d) && thin_on()) {
+            // thin-image conv layer: one (whole-output) tile, whole images per workgroup, ~one round of 256 workgroups
+            const int px = d.g_gh * d.g_gw, imgs = d.M / px;
+            const int ipw = cdiv(imgs, 256);
+            d.g_pad = 1;
+            d.tiles_n = d.tiles_k = 1;
+            d.rows_per = ipw * px;
+            d.splits = cdiv(imgs, ipw);
+        } else if (wgrad_wide()) {
             // tiles of <= 13 x 13 16-blocks, balanced; the row split is chosen below for the whole launch
             d.tiles_n = cdiv(cdiv(d.N, 16), kWB);
-            d.tiles_k = wgrad_tiles_k(cdiv(d.K + hb, 16));
+            d.tiles_k = wgrad_tiles_k(cdiv(d.N, 16), cdiv(d.K + hb, 16), wgrad_act16(d));
             d.rows_per = rows_wide;
             if (budget > 0.0) {
                 int t, c;

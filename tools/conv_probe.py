@@ -78,3 +78,36 @@ for Cin, Cout, k, size in DEC:
                                                                    [True, False, False]))
         t_own = timeit(lambda: conv.pattern_f(gys, gx, wp, None, imgs, OH, OH, Cout, k, Cin, cabi.ACT_NONE))
         print(f"     dgrad: torch {t_ref:7.3f} ms  own {t_own:7.3f} ms  ({gf / t_own:6.1f} TFLOP/s own)")
+
+
+# ---- weight gradients (bd_wgrad_grouped with a gathered window operand), one GEMM at a time, against MIOpen's ----
+print("weight gradients:")
+for Cin, Cout, k, size in ENC:
+    OH = conv.conv_out(size, k)
+    x = torch.randn(imgs, Cin, size, size, device="cuda")
+    w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.1
+    gy = torch.randn(imgs, Cout, OH, OH, device="cuda")
+    xs, gys = conv.to_nhwc(x), conv.to_nhwc(gy)
+    dW = torch.zeros(Cout, k, k, Cin, device="cuda")
+    db = torch.zeros(Cout, device="cuda")
+    desc = [conv.wgrad_desc(gys.view(imgs * OH * OH, Cout), Cout, xs, imgs, OH, OH, size, size, Cin, k, dW, db)]
+    t_own = timeit(lambda: conv.run_wgrad(desc))
+    t_ref = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
+                                                               [False, True, False]))
+    gf = 2.0 * imgs * OH * OH * k * k * Cin * Cout / 1e9
+    print(f"  conv  {Cin:4d}->{Cout:4d} k{k} (N={Cout:3d}, K={k*k*Cin:4d}, M={imgs*OH*OH:8d}): torch {t_ref:7.3f} ms  own {t_own:7.3f} ms "
+          f"({gf / t_own:6.1f} TFLOP/s own, {gf / t_ref:6.1f} torch)")
+for Cin, Cout, k, size in DEC:
+    OH = conv.convT_out(size, k)
+    x = torch.randn(imgs, Cin, size, size, device="cuda")
+    w = torch.randn(Cin, Cout, k, k, device="cuda") * 0.1
+    gy = torch.randn(imgs, Cout, OH, OH, device="cuda")
+    xs, gys = conv.to_nhwc(x), conv.to_nhwc(gy)
+    dW = torch.zeros(Cin, k, k, Cout, device="cuda")
+    desc = [conv.wgrad_desc(xs.view(imgs * size * size, Cin), Cin, gys, imgs, size, size, OH, OH, Cout, k, dW, None)]
+    t_own = timeit(lambda: conv.run_wgrad(desc))
+    t_ref = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2], [0, 0], [1, 1], True, [0, 0], 1,
+                                                               [False, True, False]))
+    gf = 2.0 * imgs * size * size * k * k * Cin * Cout / 1e9
+    print(f"  convT {Cin:4d}->{Cout:4d} k{k} (N={Cin:3d}, K={k*k*Cout:4d}, M={imgs*size*size:8d}): torch {t_ref:7.3f} ms  own {t_own:7.3f} ms "
+          f"({gf / t_own:6.1f} TFLOP/s own, {gf / t_ref:6.1f} torch)")
