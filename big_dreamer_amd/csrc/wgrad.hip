@@ -180,10 +180,12 @@ constexpr int kWStage = 2 * kWRows * kWLd;   // floats per stage: dpre rows | ac
 constexpr int kWRing = 3;             // stage buffers (DMA runs two stages ahead)
 constexpr int kWRowsTall = 32;         // rows per stage of a narrow tile (<= 64 dpre columns): half the stage overhead per row
 constexpr int kWLdNarrow = 80;         // its dpre row stride: 64 + 16, == 16 mod 32
+constexpr int kWLdMid = 144;           // dpre row stride of a mid tile (<= 128 columns): 8 blocks + 16, == 16 mod 32
 constexpr int kWLdDeep = 592;          // act row stride of a deep narrow tile: 36 blocks + pad, == 16 mod 32
 constexpr size_t kWideLdsBytes = 147456;   // >= 3 x 16 x (80 + 592) x 4 = 129 024 (deep), 3 x 32 x 320 x 4 = 122 880 (tall narrow),
                                            //    8 waves x 2 x (1280 + 1024) x 4 = 147 456 (thin-image bodies)
 static_assert((size_t)kWRing * kWRows * (kWLdNarrow + kWLdDeep) * sizeof(float) <= kWideLdsBytes, "deep stage ring");
+static_assert((size_t)kWRing * kWRowsTall * (kWLdMid + kWLd) * sizeof(float) <= kWideLdsBytes, "mid stage ring");
 constexpr int kWThreads = 512;        // 8 waves: 2 per SIMD, so LDS latency and the stage barrier hide under the other wave
 
 // WN x WK = 16-blocks per wave (the 2 x 4 waves cover up to 2WN x 4WK blocks).  The MFMA loop is branch-free: a wave
@@ -504,6 +506,11 @@ __host__ inline bool wgrad_thin_ok(const bd_wgrad_desc& d) {
     return 8 * per_wave <= kWideLdsBytes && (size_t)8 * 2 * kThinMaxKB * 1024 <= kWideLdsBytes;
 }
 
+#ifndef BD_WGRAD_TALL_MID
+#define BD_WGRAD_TALL_MID 1
+#endif
+__device__ __forceinline__ bool tall_mid() { return BD_WGRAD_TALL_MID != 0; }
+
 template <int KB>
 __device__ __forceinline__ void wgrad_thin_body(const bd_wgrad_desc& d, float* __restrict__ ws, float* wlds, int z) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -707,6 +714,23 @@ __global__ __launch_bounds__(kWThreads) void wgrad_wide_kernel(const bd_wgrad_de
 #undef BD_WN_BODY
         return;
     }
+    if (nb_cnt <= 8 && tall_mid()) {
+        // mid tile (<= 128 dpre columns: the 128-channel conv layers): 32-row stages too -- a wave holds <= 4 x 3
+        // accumulators, 48 MFMAs per 16-row stage against the same ~2.5k cycles of per-stage overhead
+#define BD_WM_BODY(WN, WK) wgrad_wide_body<WN, WK, kWRowsTall, kWLdMid>(d, ws, wlds, hb, Kext, z, n0, k0, nb_cnt, kb_cnt)
+#define BD_WM_ROW(WN)                      \
+    do {                                   \
+        if (hk <= 1) BD_WM_BODY(WN, 1);    \
+        else if (hk <= 2) BD_WM_BODY(WN, 2); \
+        else if (hk <= 3) BD_WM_BODY(WN, 3); \
+        else BD_WM_BODY(WN, 4);            \
+    } while (0)
+        if (hn <= 2) BD_WM_ROW(2);
+        else BD_WM_ROW(4);
+#undef BD_WM_ROW
+#undef BD_WM_BODY
+        return;
+    }
 #define BD_WG_BODY(WN, WK) wgrad_wide_body<WN, WK>(d, ws, wlds, hb, Kext, z, n0, k0, nb_cnt, kb_cnt)
 #define BD_WG_ROW(WN)                      \
     do {                                   \
@@ -813,6 +837,30 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
         *tiles = tn * tk;
         *cost = tile_cost(cdiv(NB, tn), cdiv(KB, tk));
     };
+    // rows per workgroup of descriptor i under budget T (thin-image layers have their own fixed split: whole images)
+    auto thin = [&](const bd_wgrad_desc& d) { return wgrad_wide() && thin_on() && wgrad_thin_ok(d); };
+    auto rows_for = [&](const bd_wgrad_desc& d, double T) {
+        int t, c;
+        desc_geo(d, &t, &c);
+        long r = (long)(T / c);
+        r = (r / kWRows) * kWRows;
+        return (int)(r < 4 * kWRows ? 4 * kWRows : (r > (1 << 22) ? (1 << 22) : r));
+    };
+    auto blocks_for = [&](double T) {
+        long b = 0;
+        for (int i = 0; i < n; ++i) {
+            const bd_wgrad_desc& d = descs[i];
+            if (thin(d)) {
+                const int imgs = d.M / (d.g_gh * d.g_gw);
+                b += cdiv(imgs, cdiv(imgs, 256));
+                continue;
+            }
+            int t, c;
+            desc_geo(d, &t, &c);
+            b += (long)t * cdiv(d.M > 0 ? d.M : 1, rows_for(d, T));
+        }
+        return b;
+    };
     double budget = 0.0;
     if (wgrad_wide() && any_gather) {
         double W = 0.0;
@@ -824,7 +872,14 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
         double R = W / (256.0 * 1024.0 * 61.0);
         if (R < 1.0) R = 1.0;
         if (R > 24.0) R = 24.0;
-        budget = W / (256.0 * (double)(int)(R + 0.999));
+        const int rounds = (int)(R + 0.999);
+        budget = W / (256.0 * (double)rounds);
+        // The grid must be WHOLE rounds of the chip: rows_per is rounded per GEMM, and a launch of 258 workgroups for
+        // "one round" ran two -- the second for two workgroups (conv 64 -> 128 alone: 0.51 ms for 0.25 ms of work).  Grow the
+        // budget until the launch fits; `rounds` may grow by one when thin-image layers bring a round of their own.
+        long target = 256L * rounds;
+        if (blocks_for(budget * 8.0) > target) target += 256;
+        for (int it = 0; it < 200 && blocks_for(budget) > target; ++it) budget *= 1.02;
     }
     for (int i = 0; i < n; ++i) {
         bd_wgrad_desc& d = descs[i];
@@ -853,13 +908,7 @@ int bd_wgrad_plan(bd_wgrad_desc* descs, int n, int* total_blocks, int* total_red
             d.tiles_n = cdiv(cdiv(d.N, 16), kWB);
             d.tiles_k = wgrad_tiles_k(cdiv(d.N, 16), cdiv(d.K + hb, 16), wgrad_act16(d));
             d.rows_per = rows_wide;
-            if (budget > 0.0) {
-                int t, c;
-                desc_geo(d, &t, &c);
-                long r = (long)(budget / c);
-                r = (r / kWRows) * kWRows;
-                d.rows_per = (int)(r < 4 * kWRows ? 4 * kWRows : (r > (1 << 22) ? (1 << 22) : r));
-            }
+            if (budget > 0.0) d.rows_per = rows_for(d, budget);
             d.splits = cdiv(d.M, d.rows_per);
         } else {
             d.tiles_n = cdiv(d.N, kWT);
