@@ -221,8 +221,10 @@ _SIGS = {
     "bd_polyak": (I32, [P, P, C.c_size_t, F32, P]),
     "bd_replay_gather": (I32, [P, P, I32, I32, P, P]),
     "bd_replay_gather_pixels": (I32, [P, P, I32, I32, I32, P, P, P]),
+    "bd_replay_gather_pixels_rng": (I32, [P, P, I32, I32, I32, C.c_ulonglong, C.c_ulonglong, P, P]),
     "bd_reduce_ws_floats": (C.c_size_t, []),
     "bd_conv_gemm": (I32, [C.POINTER(ConvArgs), P]),
+    "bd_conv_thin_forward": (I32, [P, I32, I32, I32, I32, I32, P, I32, P, I32, P, P]),
     "bd_conv_pack_class": (I32, [P, P, I32, I32, I32, I32, I32, I32, I32, P]),
     "bd_conv_pack_fused": (I32, [P, P, I32, I32, I32, P]),
     "bd_elu_backward": (I32, [P, P, C.c_size_t, P]),

@@ -50,6 +50,15 @@ def pattern_f(inp: torch.Tensor, out: torch.Tensor, w_packed: torch.Tensor, bias
     cabi.check(lib.bd_conv_gemm(C.byref(a), cabi.stream()))
 
 
+def thin_f(inp: torch.Tensor, out: torch.Tensor, w_plain: torch.Tensor, bias, imgs: int, IH: int, IW: int, Cin: int, k: int,
+           act: int) -> None:
+    """pattern_f for a THIN image (Cin <= 4) and 32 output channels: out (imgs, OH, OW, 32) from the PLAIN weight matrix
+    [32][(ky, kx, c)] (a 2-D view of the stored parameter; bd_conv_thin_forward, csrc/conv.hip)."""
+    assert w_plain.dim() == 2 and w_plain.shape[0] == 32 and w_plain.shape[1] == k * k * Cin and w_plain.stride(1) == 1
+    cabi.check(lib.bd_conv_thin_forward(ptr(inp), imgs, IH, IW, Cin, k, w_plain.data_ptr(), w_plain.stride(0), ptr(bias), act,
+                                        ptr(out), cabi.stream()))
+
+
 def pattern_t(inp: torch.Tensor, out: torch.Tensor, w_classes: List[torch.Tensor], bias, imgs: int, IH: int, IW: int,
               Cin: int, k: int, N: int, OH: int, OW: int, act: int) -> None:
     """out (imgs, OH, OW, N) = convT_stride2(inp (imgs, IH, IW, Cin)) restricted to the rows/cols < OH, OW, from the four

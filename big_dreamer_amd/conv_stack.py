@@ -19,8 +19,11 @@ import torch
 from . import _cabi as cabi
 from . import conv
 
+import os
+
 lib = cabi.lib
 ptr = cabi.ptr
+THIN = os.environ.get("BD_CONV_THIN", "1") != "0"      # "0": the 3-channel-image layers on the row-tile gather kernels (A/B)
 
 ENC = [(3, 32, 4), (32, 64, 4), (64, 128, 4), (128, 256, 4)]          # (ci, co, k); input 64 -> 31 -> 14 -> 6 -> 2
 ENC_SIZES = [64, 31, 14, 6, 2]
@@ -102,8 +105,12 @@ class ConvStacks:
         for i, (ci, co, k) in enumerate(ENC):
             sz = ENC_SIZES[i + 1]
             y = e.buf(tag + f"cv_a{i + 1}", M, sz, sz, co)
-            conv.pattern_f(self.acts_enc[-1], y, self.pk_enc_f[i], e.W("encoder", f"model.{2 * i}.bias"), M, ENC_SIZES[i],
-                           ENC_SIZES[i], ci, k, co, cabi.ACT_ELU)
+            if i == 0 and THIN:         # the 3-channel image: wave-private band pipelines (bd_conv_thin_forward)
+                conv.thin_f(self.acts_enc[-1], y, e.Ws("encoder", "model.0.weight").view(co, k * k * ci),
+                            e.W("encoder", "model.0.bias"), M, ENC_SIZES[0], ENC_SIZES[0], ci, k, cabi.ACT_ELU)
+            else:
+                conv.pattern_f(self.acts_enc[-1], y, self.pk_enc_f[i], e.W("encoder", f"model.{2 * i}.bias"), M, ENC_SIZES[i],
+                               ENC_SIZES[i], ci, k, co, cabi.ACT_ELU)
             self.acts_enc.append(y)
         flat = e.buf(tag + "cv_flat", M, 1024)                 # the reference's Flatten order (c, h, w)
         cabi.check(lib.bd_image_layout(ptr(self.acts_enc[-1]), ptr(flat), M, 256, 4, 0, cabi.stream()))
@@ -156,7 +163,11 @@ class ConvStacks:
             self._colsum(wb, g, M * osz * osz, co, G(name + ".bias"))
             # d input = strided conv of g with the stored matrix [ci][(ky, kx, co)], then through the ELU of the layer below
             gi = e.buf(f"cv_gd{j + 1}", M, isz, isz, ci)
-            conv.pattern_f(g, gi, self.pk_dec_f[j], None, M, osz, osz, co, k, ci, cabi.ACT_NONE)
+            if j == 2 and THIN:         # dgrad of ConvT(32 -> 3): a k6 convolution of the 3-channel image gradient
+                conv.thin_f(g, gi, e.Ws("observation_model", f"decoder.{DEC_IDX[j]}.weight").view(ci, k * k * co), None, M, osz,
+                            osz, co, k, cabi.ACT_NONE)
+            else:
+                conv.pattern_f(g, gi, self.pk_dec_f[j], None, M, osz, osz, co, k, ci, cabi.ACT_NONE)
             cabi.check(lib.bd_elu_backward(ptr(gi), ptr(a_in), gi.numel(), cabi.stream()))
             g = gi
         # the 1x1 -> 5x5 layer as a Linear: dW[ci][(ky,kx,co)] = sum_m l0[m][ci] * g[m][(ky,kx,co)]

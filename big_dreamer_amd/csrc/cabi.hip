@@ -1,6 +1,7 @@
 // cabi.hip -- error reporting, version, weight packing, replay gather.
 #include "bd_device.h"
 #include "bd_host.h"
+#include "bd_rng.h"
 
 namespace bd {
 char* err_buf() {
@@ -47,16 +48,26 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 // (ExperienceReplay._retrieve_batch + preprocess_observation_, src/memory.py:70-85, src/utils.py:299-317):
 //   out = floor(u8 / 2^(8-bits)) / 2^bits - 0.5 + noise / 2^bits        (noise ~ U[0,1), explicit input)
 // HBM-bound byte work: 4 pixels per thread (uchar4 in, float4 noise in, float4 out), fully coalesced.
+// RNG = true (perf mode): the dequantisation noise U[0, 1) of the four pixels is one Philox4x32-10 call (bd_rng.h) instead of
+// a 16-byte read of a noise tensor that a library kernel wrote (120 MB per step at configs[2], written and read once).
+template <bool RNG>
 __global__ __launch_bounds__(256) void gather_pixels_kernel(const unsigned char* __restrict__ src,
                                                             const int64_t* __restrict__ idx, int n_idx, int pixels,
                                                             float inv_q, float inv_b, const float* __restrict__ noise,
-                                                            float* __restrict__ dst) {
+                                                            float* __restrict__ dst, Rng rng) {
     const int quads = pixels >> 2;
     const size_t total = (size_t)n_idx * quads;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const size_t r = e / quads, q = e - r * quads;
         const uchar4 u = reinterpret_cast<const uchar4*>(src + (size_t)idx[r] * pixels)[q];
-        const floatx4 nz = reinterpret_cast<const floatx4*>(noise)[e];
+        floatx4 nz;
+        if constexpr (RNG) {
+            const Philox4 p = philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), rng.stream, rng.step, rng.k0, rng.k1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nz[j] = (float)(p.x[j] >> 8) * (1.0f / 16777216.0f);       // [0, 1) as rand_like
+        } else {
+            nz = reinterpret_cast<const floatx4*>(noise)[e];
+        }
         floatx4 o;
         o[0] = floorf((float)u.x * inv_q) * inv_b - 0.5f + nz[0] * inv_b;
         o[1] = floorf((float)u.y * inv_q) * inv_b - 0.5f + nz[1] * inv_b;
@@ -96,9 +107,22 @@ int bd_replay_gather_pixels(const unsigned char* src, const int64_t* idx, int n_
                "bd_replay_gather_pixels: bad arguments");
     const size_t total = (size_t)n_idx * (pixels >> 2);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(bd::gather_pixels_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, idx, n_idx, pixels,
-                       1.0f / (float)(1 << (8 - bit_depth)), 1.0f / (float)(1 << bit_depth), noise, dst);
+    hipLaunchKernelGGL(bd::gather_pixels_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, idx, n_idx, pixels,
+                       1.0f / (float)(1 << (8 - bit_depth)), 1.0f / (float)(1 << bit_depth), noise, dst, bd::Rng{0, 0, 0, 0});
     BD_CHECK_LAUNCH("bd_replay_gather_pixels");
+    return 0;
+}
+
+int bd_replay_gather_pixels_rng(const unsigned char* src, const int64_t* idx, int n_idx, int pixels, int bit_depth,
+                                unsigned long long seed, unsigned long long step, float* dst, void* stream) {
+    BD_REQUIRE(src && idx && dst && n_idx > 0 && pixels > 0 && (pixels & 3) == 0 && bit_depth >= 1 && bit_depth <= 8,
+               "bd_replay_gather_pixels_rng: bad arguments");
+    const size_t total = (size_t)n_idx * (pixels >> 2);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bd::gather_pixels_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, idx, n_idx, pixels,
+                       1.0f / (float)(1 << (8 - bit_depth)), 1.0f / (float)(1 << bit_depth), nullptr, dst,
+                       bd::Rng{(uint32_t)seed, (uint32_t)(seed >> 32), 6u, (uint32_t)step});
+    BD_CHECK_LAUNCH("bd_replay_gather_pixels_rng");
     return 0;
 }
 

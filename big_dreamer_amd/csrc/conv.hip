@@ -456,6 +456,103 @@ static int launch_conv(const bd_conv_args& a, hipStream_t s) {
     return 0;
 }
 
+
+// ---- thin-image forward: stride-2 VALID convolution of a C <= 4 channel image into 32 channels ------------------------
+// Conv2d(3 -> 32, k4) forward (src/models.py:538) and the dgrad of ConvTranspose2d(32 -> 3, k6) (src/models.py:347: a k6
+// convolution of the 3-channel image gradient): K = 48 / 108, N = 32, 2.2-2.4 million output pixels -- 0.05-0.1 ms of MFMA
+// work that the row-tile gather (conv_gemm_kernel<8>: K = 48 floats per row, scalar gathers, a barrier per 128 rows) ran
+// in 0.5-1.1 ms.  Same scheme as the thin-image weight gradients (wgrad.hip): every WAVE is its own pipeline over the grid
+// rows it = wave, wave + 8, ... of the workgroup's images; the k image rows under a grid row are ONE contiguous piece
+// (k x IW x C floats) that the wave DMAs into its private, double-buffered LDS band; the whole weight matrix lives in
+// registers (B operand of step s: W[n][4 s + (lane >> 4)]); the A operand of pixel x, k index (ky, kx, c) is one
+// ds_read_b32 at band[ky][(2 x + kx) C + c].  No workgroup barrier at all.
+constexpr int kThinSteps = 27;            // K <= 108
+__host__ __device__ inline int thin_band_al(int k, int roww) { return (k * roww + 64 + 255) & ~255; }
+
+template <int KS>
+__global__ __launch_bounds__(kThreads) void conv_thin_f_kernel(const float* __restrict__ in, int imgs, int IH, int IW, int C,
+                                                               int kk, const float* __restrict__ W, int ldw, int K,
+                                                               const float* __restrict__ bias, int act,
+                                                               float* __restrict__ out, int gh, int gw, int ipw) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int roww = IW * C, band = kk * roww, band_al = thin_band_al(kk, roww);
+    float* mine = lds + (size_t)wave * 2 * band_al;
+    for (int i = lane; i < 2 * band_al; i += 64) mine[i] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int kq = lane >> 4, n = lane & 15;
+    float w0[KS], w1[KS];
+    int aoff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k = 4 * s + kq;
+        const bool ok = k < K;
+        w0[s] = ok ? W[(size_t)n * ldw + k] : 0.f;
+        w1[s] = ok ? W[(size_t)(16 + n) * ldw + k] : 0.f;
+        const int ky = k / (kk * C);
+        aoff[s] = ok ? ky * roww + (k - ky * kk * C) : 0;
+    }
+    const float b0 = bias ? bias[n] : 0.f, b1 = bias ? bias[16 + n] : 0.f;
+    const int img0 = blockIdx.x * ipw, img1 = min(imgs, img0 + ipw);
+    const int items = (img1 - img0) * gh;
+    const int npc = cdiv(band, 256);
+    auto issue = [&](int it, float* buf) {
+        const int img = img0 + it / gh, y = it - (it / gh) * gh;
+        const float* sb = in + ((size_t)img * IH + 2 * y) * roww;
+        for (int ch = 0; ch < npc; ++ch)
+            if (4 * lane + 256 * ch < band)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(sb + 4 * lane + 256 * ch), (lds_ptr_t)(buf + 256 * ch), 16, 0, 0);
+    };
+    auto wait_keep_newest = [&]() {
+        switch (npc) {
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    const int nrt = cdiv(gw, 16);
+    int it = wave, b = 0;
+    if (it < items) issue(it, mine);
+    for (; it < items; it += kWaves, b ^= 1) {
+        // (the output stores of the previous item are still in flight: vmcnt counts them too, and retires in order, so the
+        //  waits below also cover them -- a few hundred cycles per item that the other wave of the SIMD fills)
+        if (it + kWaves < items) {
+            issue(it + kWaves, mine + (b ^ 1) * band_al);
+            wait_keep_newest();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const float* Bd = mine + b * band_al;
+        const int img = img0 + it / gh, y = it - (it / gh) * gh;
+        float* orow = out + ((size_t)img * gh + y) * gw * 32;
+        for (int rt = 0; rt < nrt; ++rt) {
+            const float* Bx = Bd + 2 * (rt * 16 + n) * C;              // A operand row m = lane & 15 -> pixel x = 16 rt + m
+            floatx4 acc0 = floatx4{b0, b0, b0, b0}, acc1 = floatx4{b1, b1, b1, b1};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float a = Bx[aoff[s]];
+                acc0 = mfma16(a, w0[s], acc0);
+                acc1 = mfma16(a, w1[s], acc1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int x = rt * 16 + 4 * kq + r;
+                if (x < gw) {
+                    orow[x * 32 + n] = act_apply(act, acc0[r]);
+                    orow[x * 32 + 16 + n] = act_apply(act, acc1[r]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this band is refilled by the next iteration's DMA
+    }
+}
+
 }  // namespace bd
 
 extern "C" {
@@ -555,6 +652,33 @@ int bd_image_layout(const float* src, float* dst, int imgs, int C, int HW, int t
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(layout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, imgs, C, HW, to_nhwc);
     BD_CHECK_LAUNCH("bd_image_layout");
+    return 0;
+}
+
+int bd_conv_thin_forward(const float* in, int imgs, int IH, int IW, int C, int k, const float* W, int ldw, const float* bias,
+                         int act, float* out, void* stream) {
+    using namespace bd;
+    BD_REQUIRE(in && W && out && imgs > 0 && IH > 0 && IW > 0 && C >= 1 && C <= 4 && k >= 2 && IH >= k && IW >= k,
+               "bd_conv_thin_forward: bad arguments");
+    const int K = k * k * C, gh = (IH - k) / 2 + 1, gw = (IW - k) / 2 + 1, roww = IW * C;
+    BD_REQUIRE(K <= 4 * kThinSteps && ldw >= K && gw <= 32, "bd_conv_thin_forward: K = %d (<= %d), output width %d (<= 32)", K,
+               4 * kThinSteps, gw);
+    BD_REQUIRE((roww & 3) == 0 && ((uintptr_t)in & 15) == 0, "bd_conv_thin_forward: image rows must be 16-byte aligned");
+    BD_REQUIRE((size_t)imgs * gh * gw * 32 < (1ull << 31), "bd_conv_thin_forward: image batch too large");
+    const size_t lds = (size_t)kWaves * 2 * thin_band_al(k, roww) * sizeof(float);
+    const int ipw = cdiv(imgs, 512);                      // two workgroups per CU (<= 80 KB of LDS each)
+    const int grid = cdiv(imgs, ipw);
+    hipStream_t s = (hipStream_t)stream;
+    if (K <= 48) {
+        if (lds > 64 * 1024 && allow_big_lds(conv_thin_f_kernel<12>)) return -1;
+        hipLaunchKernelGGL(conv_thin_f_kernel<12>, dim3(grid), dim3(kThreads), lds, s, in, imgs, IH, IW, C, k, W, ldw, K, bias, act, out,
+                           gh, gw, ipw);
+    } else {
+        if (lds > 64 * 1024 && allow_big_lds(conv_thin_f_kernel<kThinSteps>)) return -1;
+        hipLaunchKernelGGL(conv_thin_f_kernel<kThinSteps>, dim3(grid), dim3(kThreads), lds, s, in, imgs, IH, IW, C, k, W, ldw, K, bias,
+                           act, out, gh, gw, ipw);
+    }
+    BD_CHECK_LAUNCH("bd_conv_thin_forward");
     return 0;
 }
 

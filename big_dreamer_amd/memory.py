@@ -32,6 +32,7 @@ class ExperienceReplay:
         self._dirty = True
         self._out_ring, self._out_i = {}, {}
         self._pix_noise = None
+        self._pix_seed, self._pix_step = None, 0
         self._ring = []           # pinned staging buffers for the index upload (async H2D, no host stall)
         self._ring_i = 0
 
@@ -119,14 +120,14 @@ class ExperienceReplay:
         if self.pixel_observation:
             src = self._dev["observations"]
             pixels = 3 * 64 * 64
-            # persistent buffers (no allocator traffic per step): the noise is consumed by the gather right behind it on
-            # the same stream; the batch comes from the same ring of four as the other arrays
-            if self._pix_noise is None or self._pix_noise.numel() != L * n * pixels:
-                self._pix_noise = torch.empty(L * n * pixels, dtype=torch.float32, device=self.device)
-            noise = self._pix_noise.uniform_()                                              # rand_like, src/utils.py:317
+            # dequantisation noise (rand_like, src/utils.py:317) drawn inside the gather kernel: Philox keyed by the torch
+            # seed at the first sample, counter = sample index (no noise tensor, no library RNG launch per step)
+            if self._pix_seed is None:
+                self._pix_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
             dst = self._out("pixels", L * n * pixels)
-            cabi.check(cabi.lib.bd_replay_gather_pixels(src.data_ptr(), vidx.data_ptr(), L * n, pixels, self.bit_depth,
-                                                        noise.data_ptr(), dst.data_ptr(), cabi.stream()))
+            cabi.check(cabi.lib.bd_replay_gather_pixels_rng(src.data_ptr(), vidx.data_ptr(), L * n, pixels, self.bit_depth,
+                                                            self._pix_seed, self._pix_step, dst.data_ptr(), cabi.stream()))
+            self._pix_step += 1
             out.append(dst.view(L, n, 3, 64, 64))
         for key, shape in (("observations", (L, n, -1)), ("actions", (L, n, -1)), ("rewards", (L, n)),
                            ("nonterminals", (L, n, 1))):

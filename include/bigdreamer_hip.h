@@ -161,6 +161,12 @@ typedef struct {
                            * gh x gw = the class-(0,0) grid; bias indexed by c); 0 = one class per call                */
 } bd_conv_args;
 int bd_conv_gemm(const bd_conv_args* a, void* stream);
+/* Stride-2 VALID convolution of a THIN image (C <= 4 channels) into 32 channels, NHWC: out (imgs, OH, OW, 32) =
+ * act(conv(in (imgs, IH, IW, C), W) + bias), W plain row-major [32][(ky, kx, c)] with row stride ldw (the stored parameter
+ * as it lies in the buffer; bias may be NULL).  Conv2d(3 -> 32, k4) forward (src/models.py:538) and the dgrad of
+ * ConvTranspose2d(32 -> 3, k6) (src/models.py:347).  k*k*C <= 108, OW <= 32. */
+int bd_conv_thin_forward(const float* in, int imgs, int IH, int IW, int C, int k, const float* W, int ldw, const float* bias,
+                         int act, float* out, void* stream);
 /* dst (packed) [n = inner][k = (a, b', outer)] = src[outer][py+2a][px+2(Tb-1-b')][inner], src stored (outer, ky, kx, inner) */
 int bd_conv_pack_class(const float* src, float* dst, int Couter, int Cinner, int ksz, int py, int px, int Ta, int Tb,
                        void* stream);
@@ -598,6 +604,10 @@ int bd_replay_gather(const float* src, const int64_t* idx, int n_idx, int width,
  * noise ~ U[0,1) is an explicit [n_idx x pixels] input) */
 int bd_replay_gather_pixels(const unsigned char* src, const int64_t* idx, int n_idx, int pixels, int bit_depth,
                             const float* noise, float* dst, void* stream);
+/* The same with the dequantisation noise U[0, 1) drawn in the kernel (Philox4x32-10, csrc/bd_rng.h; stream 6 of `seed`,
+ * counter = element quad, `step`): perf mode -- no noise tensor, no library RNG launch. */
+int bd_replay_gather_pixels_rng(const unsigned char* src, const int64_t* idx, int n_idx, int pixels, int bit_depth,
+                                unsigned long long seed, unsigned long long step, float* dst, void* stream);
 
 size_t bd_reduce_ws_floats(void);
 

@@ -167,3 +167,27 @@ def test_plain_gemm_nt_matches_cpu_fp32(M, N, K, acc):
     assert torch.equal(got[:, N:], C0[:, N:]), "columns beyond N were written"
     err = float((got[:, :N].double() - ref).abs().max())
     assert err <= 2e-5 * float(ref.abs().max()) + 1e-6, err
+
+
+@pytest.mark.parametrize("imgs,k,bias,act", [(5, 4, True, True), (13, 6, False, False), (1, 4, False, True), (700, 6, True, False)])
+def test_thin_image_conv_forward_matches_cpu_fp32(imgs, k, bias, act):
+    """bd_conv_thin_forward (csrc/conv.hip): stride-2 VALID convolution of the 3-channel 64 x 64 image into 32 channels --
+    Conv2d(3 -> 32, k4) forward and, with k6, the dgrad of ConvTranspose2d(32 -> 3, k6) -- against F.conv2d on the CPU."""
+    from big_dreamer_amd import _cabi as cabi, conv
+    g = torch.Generator().manual_seed(imgs + k)
+    x = torch.randn(imgs, 3, 64, 64, generator=g)
+    w = torch.randn(32, 3, k, k, generator=g) * 0.2
+    b = torch.randn(32, generator=g) if bias else None
+    ref = Fnn.conv2d(x, w, b, stride=2)
+    if act:
+        ref = Fnn.elu(ref)
+    OH = conv.conv_out(64, k)
+    xs = conv.to_nhwc(x.cuda())
+    # the stored layout (co, ky, kx, ci) at an odd float offset of a larger buffer, as in the flat parameter buffer
+    wbuf = torch.zeros(32 * k * k * 3 + 8, device="cuda")
+    ws = wbuf[4:4 + 32 * k * k * 3].view(32, k * k * 3)
+    ws.copy_(w.permute(0, 2, 3, 1).reshape(32, -1))
+    out = torch.full((imgs, OH, OH, 32), float("nan"), device="cuda")
+    conv.thin_f(xs, out, ws, b.cuda() if bias else None, imgs, 64, 64, 3, k, cabi.ACT_ELU if act else cabi.ACT_NONE)
+    torch.cuda.synchronize()
+    _close(out.permute(0, 3, 1, 2), ref, 2e-5)

@@ -112,3 +112,28 @@ def test_in_kernel_entropy_draws_match_the_explicit_noise_estimator_in_distribut
     # per-row: the two estimators scatter around each other like two independent draws of the same estimator
     assert abs(np.std(e0 - e1) / np.std(e1 - e2) - 1.0) < 0.1
     assert abs(s0.mean(0) - s1.mean(0)).max() < 6 * np.sqrt((s1 - s2).var(0).max() / len(e0))
+
+
+def test_pixel_gather_with_in_kernel_noise_is_the_reference_dequantisation():
+    """bd_replay_gather_pixels_rng: floor(u8 / 2^(8-bits)) / 2^bits - 0.5 + U[0,1) / 2^bits (preprocess_observation_,
+    src/utils.py:299-317) with the uniform drawn in the kernel: the quantised part is exact, the noise part lies in [0, 1),
+    is uniform, differs between steps and is reproducible."""
+    from scipy import stats
+    from big_dreamer_amd import _cabi as cabi
+    rows, n_idx, pixels, bits = 9, 40, 3 * 64 * 64, 5
+    g = torch.Generator().manual_seed(1)
+    u8 = torch.randint(0, 256, (rows, pixels), dtype=torch.uint8, generator=g).cuda()
+    idx = torch.randint(0, rows, (n_idx,), dtype=torch.int64, generator=g).cuda()
+    outs = []
+    for step in (0, 0, 1):
+        dst = torch.zeros(n_idx, pixels, device="cuda")
+        cabi.check(cabi.lib.bd_replay_gather_pixels_rng(u8.data_ptr(), idx.data_ptr(), n_idx, pixels, bits, 77, step,
+                                                        dst.data_ptr(), cabi.stream()))
+        torch.cuda.synchronize()
+        outs.append(dst)
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+    q = torch.floor(u8[idx].float() / 2 ** (8 - bits))
+    noise = ((outs[0] + 0.5) * 2 ** bits - q).cpu().double().numpy().reshape(-1)
+    assert noise.min() >= -1e-5 and noise.max() < 1.0 + 1e-5
+    assert abs(noise.mean() - 0.5) < 1e-3 and abs(noise.var() - 1.0 / 12.0) < 1e-3
+    assert stats.kstest(np.clip(noise[:200000], 0.0, 1.0), "uniform").pvalue > 1e-4
