@@ -185,6 +185,7 @@ _SIGS = {
     "bd_observe_cluster_status": (I32, [P, I32, P]),
     "bd_observe_cluster_err_offset": (C.c_size_t, [I32]),
     "bd_observe_cluster_set_spin_limit": (I32, [C.c_uint]),
+    "bd_observe_cluster_set_ksplit": (I32, [I32]),
     "bd_gauss_head_forward": (I32, [P, P, I32, I32, F32, P, P, P, P]),
     "bd_gauss_head_backward": (I32, [P, P, P, P, P, I32, I32, P, P]),
     "bd_observe_cat_forward": (I32, [C.POINTER(ObserveCatFwdArgs), P]),

@@ -100,4 +100,12 @@ inline size_t launch_lds(K kernel, size_t need, const char* who) {
     return (e && e[0] == '0') ? need : room;
 }
 
+// K-split form of the Gaussian cluster scan (observe_ksplit.hip): used by bd_observe_forward_cluster / _backward_cluster when
+// the cluster has one member per 16-column belief block (ksplit_ok); BD_OBS_KSPLIT=0 keeps the round-1 form
+size_t ksplit_ws_floats_per_tile(int C);
+bool ksplit_ok(int Be, int S, int A, int Hd, int C);
+int& ksplit_mode();
+int launch_observe_kfwd(const bd_observe_fwd_args* a, float* ws, int C, int tiles, hipStream_t stream);
+int launch_observe_kbwd(const bd_observe_bwd_args* a, float* ws, int C, int tiles, hipStream_t stream);
+
 }  // namespace bd

@@ -572,10 +572,20 @@ int bd_observe_cluster_size(int B, int Be) { return pick_cluster(B, Be); }
 
 size_t bd_observe_cluster_ws_floats(int B, int Be) {
     const int tiles = cdiv(B, 16);
-    return cluster_ws_header_floats(tiles) + (size_t)tiles * 2 * 2 * cdiv(Be, 16) * kFragFloats;
+    size_t per_tile = (size_t)2 * 2 * cdiv(Be, 16) * kFragFloats;
+    const int C = pick_cluster(B, Be);
+    if (C > 0 && ksplit_ws_floats_per_tile(C) > per_tile) per_tile = ksplit_ws_floats_per_tile(C);   // K-split form (observe_ksplit.hip)
+    return cluster_ws_header_floats(tiles) + (size_t)tiles * per_tile;
 }
 
 size_t bd_observe_cluster_err_offset(int B) { return cluster_ws_flag_floats(cdiv(B, 16)); }
+
+// which cluster form bd_observe_forward_cluster / _backward_cluster run: 1 = the K-split form (observe_ksplit.hip) wherever
+// it applies, 0 = the round-1 form (GRU columns split, the rest redundant), -1 = default (K-split unless BD_OBS_KSPLIT=0)
+int bd_observe_cluster_set_ksplit(int mode) {
+    ksplit_mode() = mode < 0 ? -1 : (mode ? 1 : 0);
+    return 0;
+}
 
 int bd_observe_cluster_set_spin_limit(unsigned limit) {
     cluster_spin_limit() = limit ? limit : kSpinLimit;
@@ -612,6 +622,11 @@ int bd_observe_forward_cluster(const bd_observe_fwd_args* a, float* ws, size_t w
     const size_t lds = ((size_t)(3 * d.Kb_h + d.Kb_hd + d.Kb_s + d.Kb_a) * kFragFloats + 16 * a->S + scratch_floats_fwd()) *
                        sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_observe_forward_cluster: needs %zu B of LDS", lds);
+    if (ksplit_ok(a->Be, a->S, a->A, a->Hd, C)) {        // every layer split along K over the members, weights in registers
+        if (hipMemsetAsync(ws, 0, cluster_ws_flag_floats(tiles) * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return fail("bd_observe_forward_cluster: memset failed");
+        return launch_observe_kfwd(a, ws, C, tiles, (hipStream_t)stream);
+    }
     if (allow_big_lds(observe_cfwd_kernel)) return -1;
     const size_t dyn = launch_lds(observe_cfwd_kernel, lds, "bd_observe_forward_cluster");
     if (!dyn) return -1;
@@ -638,6 +653,11 @@ int bd_observe_backward_cluster(const bd_observe_bwd_args* a, float* ws, size_t 
     const size_t lds = ((size_t)(6 * d.Kb_h + d.Kb_hd + 2 * d.Kb_s) * kFragFloats + 16 * a->S + scratch_floats_bwd()) *
                        sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_observe_backward_cluster: needs %zu B of LDS", lds);
+    if (ksplit_ok(a->Be, a->S, a->A, a->Hd, C)) {
+        if (hipMemsetAsync(ws, 0, cluster_ws_flag_floats(tiles) * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return fail("bd_observe_backward_cluster: memset failed");
+        return launch_observe_kbwd(a, ws, C, tiles, (hipStream_t)stream);
+    }
     if (allow_big_lds(observe_cbwd_kernel)) return -1;
     const size_t dyn = launch_lds(observe_cbwd_kernel, lds, "bd_observe_backward_cluster");
     if (!dyn) return -1;

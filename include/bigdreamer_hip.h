@@ -258,6 +258,13 @@ int bd_observe_backward(const bd_observe_bwd_args* a, void* stream);
  * seconds) exists so that tests can force a time-out.  The launches return an error (never abort the queue) when the
  * kernel's static + dynamic LDS would exceed the CU's 160 KiB. */
 int bd_observe_cluster_size(int B, int Be);   /* workgroups per 16-row tile; 0 = use bd_observe_forward/backward */
+/* Two cluster forms sit behind the same calls.  Round 3 (csrc/observe_ksplit.hip, the default where the cluster has one
+ * member per 16-column belief block and Hd <= Be): EVERY layer of the step is split along K over the members with the
+ * weight slices resident in registers -- gate partials reduce-scatter, posterior-hidden partials reduce-scatter, head
+ * partials all-reduce: three hand-offs per step, nothing computed redundantly.  Round 1 (csrc/observe_cluster.hip, wide
+ * batches with two belief blocks per member, or bd_observe_cluster_set_ksplit(0)): only the GRU is split, by output
+ * columns, one all-gather per step, the small layers recomputed by every member.  Identical arguments and results. */
+int bd_observe_cluster_set_ksplit(int mode);  /* 1 / 0 / -1 = default (environment BD_OBS_KSPLIT)                  */
 size_t bd_observe_cluster_ws_floats(int B, int Be);
 int bd_observe_forward_cluster(const bd_observe_fwd_args* a, float* ws, size_t ws_floats, void* stream);
 int bd_observe_backward_cluster(const bd_observe_bwd_args* a, float* ws, size_t ws_floats, void* stream);

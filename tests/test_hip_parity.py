@@ -96,6 +96,8 @@ def test_forward_pieces_vs_oracle(name):
 @pytest.mark.parametrize("name,cluster", [("tiny", True), ("small", True), ("tiny_klsum", True), ("tiny_freenats0", True),
                                           ("config1", True), ("config2", True), ("small", False),
                                           ("tiny_freenats0", False), ("config2", False),
+                                          # the round-1 cluster form (GRU columns split, one all-gather per step)
+                                          ("small", "round1"), ("tiny_freenats0", "round1"), ("config2", "round1"),
                                           ("tiny_pixel", True), ("tiny_pixel_lin", True),
                                           ("tiny_pixel", "miopen"), ("tiny_pixel_lin", "miopen"),
                                           ("config3", True), ("tiny_discount", True), ("tiny_discount", False)])
@@ -103,8 +105,14 @@ def test_train_steps_vs_oracle_and_golden(name, cluster, monkeypatch):
     """Two whole train steps: losses, clipped gradients, gradient norms, post-Adam weights -- with the observe
     scan run by the multi-CU cluster kernels (default) and by the single-workgroup kernels."""
     from oracle import dreamer_oracle as O
+    from big_dreamer_amd import _cabi as cabi
     torch_convs = cluster == "miopen"
     if torch_convs:
+        cluster = True
+    # cluster=True: the K-split cluster scan (csrc/observe_ksplit.hip, the default); "round1": observe_cluster.hip's form;
+    # False: one workgroup per tile (observe.hip)
+    cabi.check(cabi.lib.bd_observe_cluster_set_ksplit(0 if cluster == "round1" else -1))
+    if cluster == "round1":
         cluster = True
     d, seed, hp, full, g, P, batch, noise, eng = _setup(name, cluster)
     if d.pixel:
@@ -154,6 +162,7 @@ def test_train_steps_vs_oracle_and_golden(name, cluster, monkeypatch):
                     _rel(f"s{step}.param.{mod}.{k}", got, p.detach().numpy(), 2e-5, 1e-5, rep)
                     compare_tensor(g, f"step{step}.param.{mod}.{k}", got, full, atol=2e-5, rtol=1e-5)
     finally:
+        cabi.check(cabi.lib.bd_observe_cluster_set_ksplit(-1))
         print("\n".join(rep[-400:]))
 
 
