@@ -11,7 +11,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 B="--no-cpu-baseline --no-secondary"
 if [ "$WHAT" = "all" ] || [ "$WHAT" = "main" ]; then
-timeout -k 10 400 python3 bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err || exit 1
+timeout -k 10 500 python3 bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 10 --warmup 2 $B > $OUT/stats.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 $B > $OUT/pmc_fetch.log 2>&1 || exit 1

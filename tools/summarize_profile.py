@@ -40,8 +40,9 @@ def pmc(sub, select=None):
 
 def traffic_of(fe, wr, sq, names):
     out = {}
-    for key, frag in names.items():
-        kn = [k for k in fe if frag in k]
+    for key, frags in names.items():
+        # a name fragment or a list of alternatives (kernels renamed between rounds: first one present wins)
+        kn = [k for frag in ([frags] if isinstance(frags, str) else frags) for k in fe if frag in k]
         if not kn:
             continue
         k = kn[0]
@@ -84,11 +85,11 @@ if os.path.exists(os.path.join(src, "bench.json")):
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
     stats_csv = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
     shutil.copy(stats_csv, os.path.join(dst, f"{tag}_kernel_stats.csv"))
-    names = {"imagine_fwd": "imagine_fwd_kernel", "imagine_bwd": "imagine_bwd_kernel", "observe_fwd": "observe_cfwd_kernel",
-             "observe_bwd": "observe_cbwd_kernel", "mlp_fwd_tall (34 300-row chains, mean)": "mlp_fwd_tall_kernel",
+    names = {"imagine_fwd": "imagine_fwd_kernel", "imagine_bwd": "imagine_bwd_kernel", "observe_fwd": ["observe_kfwd_kernel", "observe_cfwd_kernel"],
+             "observe_bwd": ["observe_kbwd_kernel", "observe_cbwd_kernel"], "mlp_fwd_tall (34 300-row chains, mean)": "mlp_fwd_tall_kernel",
              "mlp_bwd_tall (34 300-row chains, mean)": "mlp_bwd_tall_kernel", "mlp_fwd (all launches, mean)": "mlp_fwd_kernel",
              "mlp_bwd (all launches, mean)": "mlp_bwd_kernel", "wgrad_wide (all launches, mean)": "wgrad_wide_kernel",
-             "dense_ws (all launches, mean)": "dense_ws"}
+             "actor_entropy (in-kernel Philox draws)": "actor_entropy_kernel"}
     traffic = traffic_of(pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq"), names)
     json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
     dom = bench["roofline"]["kernel"]
@@ -138,6 +139,8 @@ if os.path.exists(os.path.join(src, "pixel_bench.json")):
     names = {"wgrad_decoder": "wgrad_wide_kernel", "conv_gemm<1>": "conv_gemm_kernel<1>", "conv_gemm<2>": "conv_gemm_kernel<2>",
              "conv_gemm<4>": "conv_gemm_kernel<4>", "conv_gemm<8>": "conv_gemm_kernel<8>", "conv_patch<1>": "conv_patch_kernel<1>",
              "conv_patch<2>": "conv_patch_kernel<2>", "conv_patch<8>": "conv_patch_kernel<8>",
+             "conv_thin_f<12> (Conv2d 3->32 forward)": "conv_thin_f_kernel<12>", "conv_thin_f<27> (ConvT 32->3 dgrad)": "conv_thin_f_kernel<27>",
+             "gemm_nt_dma (K = 3200 dgrad)": "gemm_nt_dma_kernel",
              "imagine_fwd (A=17)": "imagine_fwd_kernel", "imagine_bwd (A=17)": "imagine_bwd_kernel"}
     ptraffic = traffic_of(counter("pixel_pmc_fetch"), counter("pixel_pmc_write"), counter("pixel_pmc_sq"), names)
     if "wgrad_decoder" in ptraffic:
@@ -159,7 +162,8 @@ if os.path.exists(os.path.join(src, "cat_bench.json")):
     cstats = glob.glob(os.path.join(src, "cat_stats", "*", "*_kernel_stats.csv"))[0]
     shutil.copy(cstats, os.path.join(dst, f"{tag}_cat_kernel_stats.csv"))
     names = {"imagine_fwd": "imagine_cat_fwd_kernel", "imagine_bwd": "imagine_cat_bwd_kernel",
-             "observe_fwd": "observe_cat_fwd_kernel", "observe_bwd": "observe_cat_bwd_kernel",
+             "observe_fwd": ["observe_cat_cfwd_kernel", "observe_cat_fwd_kernel"],
+             "observe_bwd": ["observe_cat_cbwd_kernel", "observe_cat_bwd_kernel"],
              "mlp_fwd (all launches, mean)": "mlp_fwd_kernel", "mlp_bwd (all launches, mean)": "mlp_bwd_kernel",
              "wgrad_wide (all launches, mean)": "wgrad_wide_kernel"}
     ctraffic = traffic_of(pmc("cat_pmc_fetch"), pmc("cat_pmc_write"), pmc("cat_pmc_sq"), names)
