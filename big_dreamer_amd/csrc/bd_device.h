@@ -300,6 +300,8 @@ struct NoPre {
 
 // Diagnostic build only (-DBD_STAMPS): s_memtime at points inside a tile primitive, recorded by thread 0 of workgroup 0
 // when the caller passes a slot base >= 0 (each translation unit has its own table).  Never in the shipped .so.
+// The slot bound matters: primitives forward `sb + 16` to the primitives nested in them, and an unchecked base of 48 once
+// stamped slots 64-69 -- past the table, into the unmapped page behind the module's data segment (gpurun_out/stamps39.log).
 #ifdef BD_STAMPS
 #ifndef BD_STAMP_BLOCK
 #define BD_STAMP_BLOCK 0          // workgroup that records (-DBD_STAMP_BLOCK=n)
