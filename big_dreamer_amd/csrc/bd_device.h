@@ -298,6 +298,19 @@ struct NoPre {
     __device__ __forceinline__ NoPreVal operator()(int, int) const { return NoPreVal{}; }
 };
 
+// Stores of activations that are saved for the backward pass (written once, read once much later): with -DBD_NT_SAVES=1
+// they carry the non-temporal hint, so that the stream of saves does not push the step's weights out of the XCD's L2.
+#ifndef BD_NT_SAVES
+#define BD_NT_SAVES 0
+#endif
+__device__ __forceinline__ void st_save(float* p, float v) {
+#if BD_NT_SAVES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // Diagnostic build only (-DBD_STAMPS): s_memtime at points inside a tile primitive, recorded by thread 0 of workgroup 0
 // when the caller passes a slot base >= 0 (each translation unit has its own table).  Never in the shipped .so.
 // The slot bound matters: primitives forward `sb + 16` to the primitives nested in them, and an unchecked base of 48 once

@@ -60,7 +60,7 @@ struct HiddenEpi {
             if (save) {
                 float* __restrict__ s = save + tn * width + ((unsigned)(row0 + 4 * q) * (unsigned)width + (unsigned)(nb * 16 + c));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[(unsigned)r * (unsigned)width] = v[r];
+                for (int r = 0; r < 4; ++r) st_save(s + (unsigned)r * (unsigned)width, v[r]);
             }
             return;
         }

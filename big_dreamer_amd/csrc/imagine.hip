@@ -211,14 +211,14 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
                 const unsigned lo = (unsigned)(row0 + 4 * q), cc = (unsigned)(nb * 16 + c);
                 float* __restrict__ f = a.feat + tn * F + (lo * (unsigned)F + cc);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) f[(unsigned)r * (unsigned)F] = hn[r];
+                for (int r = 0; r < 4; ++r) st_save(f + (unsigned)r * (unsigned)F, hn[r]);
                 if (a.sv_gates) {
                     const unsigned Be = (unsigned)a.Be;
                     float* __restrict__ g = a.sv_gates + tn * 4 * a.Be + (lo * 4u * Be + cc);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float* gr = g + (unsigned)r * 4u * Be;
-                        gr[0] = rr[r]; gr[Be] = zz[r]; gr[2u * Be] = nn[r]; gr[3u * Be] = NH[r];
+                        st_save(gr, rr[r]); st_save(gr + Be, zz[r]); st_save(gr + 2u * Be, nn[r]); st_save(gr + 3u * Be, NH[r]);
                     }
                 }
                 return;

@@ -580,10 +580,11 @@ size_t bd_observe_cluster_ws_floats(int B, int Be) {
 
 size_t bd_observe_cluster_err_offset(int B) { return cluster_ws_flag_floats(cdiv(B, 16)); }
 
-// which cluster form bd_observe_forward_cluster / _backward_cluster run: 1 = the K-split form (observe_ksplit.hip) wherever
-// it applies, 0 = the round-1 form (GRU columns split, the rest redundant), -1 = default (K-split unless BD_OBS_KSPLIT=0)
+// which cluster form bd_observe_forward_cluster / _backward_cluster run wherever the K-split form applies: 2 = K-split with
+// granule hand-offs (observe_ksplit.hip, form R2), 1 = K-split with flag hand-offs (R1), 0 = the round-1 form (GRU columns
+// split, the rest redundant), -1 = default (environment BD_OBS_KSPLIT, else 1)
 int bd_observe_cluster_set_ksplit(int mode) {
-    ksplit_mode() = mode < 0 ? -1 : (mode ? 1 : 0);
+    ksplit_mode() = mode < 0 ? -1 : (mode > 2 ? 2 : mode);
     return 0;
 }
 
@@ -622,11 +623,8 @@ int bd_observe_forward_cluster(const bd_observe_fwd_args* a, float* ws, size_t w
     const size_t lds = ((size_t)(3 * d.Kb_h + d.Kb_hd + d.Kb_s + d.Kb_a) * kFragFloats + 16 * a->S + scratch_floats_fwd()) *
                        sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_observe_forward_cluster: needs %zu B of LDS", lds);
-    if (ksplit_ok(a->Be, a->S, a->A, a->Hd, C)) {        // every layer split along K over the members, weights in registers
-        if (hipMemsetAsync(ws, 0, cluster_ws_flag_floats(tiles) * sizeof(float), (hipStream_t)stream) != hipSuccess)
-            return fail("bd_observe_forward_cluster: memset failed");
-        return launch_observe_kfwd(a, ws, C, tiles, (hipStream_t)stream);
-    }
+    if (ksplit_ok(a->Be, a->S, a->A, a->Hd, C))          // every layer split along K over the members, weights in registers
+        return launch_observe_kfwd(a, ws, C, tiles, (hipStream_t)stream);      // (zeroes what its hand-off form polls)
     if (allow_big_lds(observe_cfwd_kernel)) return -1;
     const size_t dyn = launch_lds(observe_cfwd_kernel, lds, "bd_observe_forward_cluster");
     if (!dyn) return -1;
@@ -653,11 +651,7 @@ int bd_observe_backward_cluster(const bd_observe_bwd_args* a, float* ws, size_t 
     const size_t lds = ((size_t)(6 * d.Kb_h + d.Kb_hd + 2 * d.Kb_s) * kFragFloats + 16 * a->S + scratch_floats_bwd()) *
                        sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_observe_backward_cluster: needs %zu B of LDS", lds);
-    if (ksplit_ok(a->Be, a->S, a->A, a->Hd, C)) {
-        if (hipMemsetAsync(ws, 0, cluster_ws_flag_floats(tiles) * sizeof(float), (hipStream_t)stream) != hipSuccess)
-            return fail("bd_observe_backward_cluster: memset failed");
-        return launch_observe_kbwd(a, ws, C, tiles, (hipStream_t)stream);
-    }
+    if (ksplit_ok(a->Be, a->S, a->A, a->Hd, C)) return launch_observe_kbwd(a, ws, C, tiles, (hipStream_t)stream);
     if (allow_big_lds(observe_cbwd_kernel)) return -1;
     const size_t dyn = launch_lds(observe_cbwd_kernel, lds, "bd_observe_backward_cluster");
     if (!dyn) return -1;

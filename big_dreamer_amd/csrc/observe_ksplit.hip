@@ -44,29 +44,137 @@ constexpr int kKsMaxA = 2;        // action blocks (A <= 32)
 // The stored value is an MFMA accumulator: the hazard recogniser does not see an inline-asm READ of a register an MFMA is
 // still writing (v_mfma_f32_16x16x4_f32 = 8 passes: 11 wait states before a VMEM read of its result; without them one
 // component of the float4 left stale -- every fourth belief column wrong, tools/ks_debug.py), so the wait states are spelled out.
+// The other direction too: a store of more than 8 bytes keeps reading its data registers for two wait states after issue
+// (the compiler's ">64-bit store data" hazard, which it cannot apply to an asm block); the granule form rewrites the staging
+// tuple with the very next v_mov, and without the trailing s_nop the last lanes of each quarter sent the NEXT value.
 __device__ __forceinline__ void ks_store4(float* p, floatx4 v) {
-    asm volatile("s_nop 7\n\ts_nop 3\n\tglobal_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("s_nop 7\n\ts_nop 3\n\tglobal_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ floatx4 ks_load4(const float* p) {
     const unsigned long long lo = ld_sc1_u64(p), hi = ld_sc1_u64(p + 2);
     return floatx4{__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
                    __uint_as_float((unsigned)(hi >> 32))};
 }
-// sum over the members src = first, first + stride, ... < C of one 1 KiB accumulator image (this lane's float4), in member
-// order.  All loads are issued before the first add (up to 16 members: C <= kMaxCluster): one L2 round trip, not one per batch.
-__device__ __forceinline__ floatx4 ks_sum(const float* base, size_t src_stride, int first, int stride, int C, int lane) {
-    const float* p = base + lane * 4;
-    floatx4 v[kMaxCluster];
-#pragma unroll
-    for (int i = 0; i < kMaxCluster; ++i) {
-        const int src = first + i * stride;
-        v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-        if (src < C) v[i] = ks_load4(p + (size_t)src * src_stride);
+// ---- hand-off forms ---------------------------------------------------------------------------------------------------------
+// GR = false: form R1 of bd_cluster.h (sc1 payload -> vmcnt(0) -> barrier -> flag; one wave polls the flags -> barrier -> sc1
+//   loads).  s_memtime: a hand-off costs ~7k cycles end to end (publish 2k, poll 2.5-3.4k, the payload's own round trip 2k).
+// GR = true (BD_OBS_KSPLIT=2; parity-tested, NOT the default -- measured below): form R2 of the guide ("the data IS the flag", cdna_hip_programming.md Guideline 16): every value travels in a
+//   naturally aligned 8-byte granule {tag = epoch, value}; a float4 of a lane becomes two 16-byte sc1 stores
+//   {tag, v0, tag, v1}, {tag, v2, tag, v3} (each 8-byte half of a 16-byte sc1 store is observed untorn on gfx950:
+//   MI355X_MICROARCH.md, Valid forms), and the consumer polls the granules it is about to sum until every tag carries the
+//   epoch -- no drain, no flag, no barrier, no second round trip.  Tags restart at 1 in every launch, so the launch function
+//   zeroes the exchange buffer (a memset node ahead of the kernel); spins are bounded and end in the sticky error word.
+//   Buffer reuse: every hand-off is all-to-all (a member passes hand-off k only when ALL members have stored for k, which
+//   they do after finishing their reads of hand-off k - 1), so a region is rewritten at the next time step at the earliest
+//   two full hand-offs after its last reader finished: one copy, no parity double-buffering.
+//   Measured (tools/ks_stamps.py, member 0, cycles per step): forward 34.0k (R1) vs 36.8k (R2), backward 32.9k vs 31.9k; the
+//   gate hand-off (52 KB of partials per member, 104 KB as granules) went from 12.3k to 15.1k, the two small ones gained 0.5k
+//   each.  So the floor of a hand-off here is NOT the flag's extra round trip: it is the ~6k cycles (2.5 us) that a
+//   write-through store takes to become readable from another CU while eight waves per CU keep the memory queue busy
+//   (the guide's handoff-1to1 row under load), and doubling the bytes costs more than the saved round trip returns.
+// An image = the float4 of 64 lanes: 256 floats (R1) or 512 (R2: chunk 0 = {tag, v0, tag, v1} of every lane, chunk 1 the rest).
+template <bool GR> struct KsImg { static constexpr int floats = GR ? 512 : 256; };
+
+template <bool GR>
+__device__ __forceinline__ void ks_emit(float* img, int lane, floatx4 v, unsigned epoch) {
+    if constexpr (GR) {
+        const float tg = __uint_as_float(epoch);
+        ks_store4(img + lane * 4, floatx4{tg, v[0], tg, v[1]});
+        ks_store4(img + 256 + lane * 4, floatx4{tg, v[2], tg, v[3]});
+    } else {
+        ks_store4(img + lane * 4, v);
     }
-    floatx4 s = v[0];
+}
+
+constexpr int kKsChunk = 8;        // members whose loads one poll / sum pass keeps in flight (64 VGPRs either way)
+
+// sum over the members src = first, first + stride, ... < C of one image (this lane's float4), in member order.
+// R1: the caller has passed wait_all; all loads of a chunk are issued before the first add.
+// R2: polls.  A probe pass re-reads ONE granule per member until its tag matches (cheap while the producers are still
+// busy), then the full sweep loads the other three and checks every tag again (a mismatch there just repeats the pass).
+template <bool GR>
+__device__ __forceinline__ floatx4 ks_reduce(const float* base, size_t src_stride, int first, int stride, int C, int lane,
+                                             unsigned epoch, unsigned* err, unsigned limit, unsigned code, bool& dead) {
+    floatx4 s = floatx4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (!GR) {
+        const float* p = base + lane * 4;
+        for (int m0 = first; m0 < C; m0 += kKsChunk * stride) {
+            floatx4 v[kKsChunk];
 #pragma unroll
-    for (int i = 1; i < kMaxCluster; ++i) s += v[i];
-    return s;
+            for (int i = 0; i < kKsChunk; ++i) {
+                const int src = m0 + i * stride;
+                v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (src < C) v[i] = ks_load4(p + (size_t)src * src_stride);
+            }
+#pragma unroll
+            for (int i = 0; i < kKsChunk; ++i) s += v[i];
+        }
+        return s;
+    } else {
+        const float* p = base + lane * 4;
+        unsigned spins = 0;       // `dead` is the wave's: after one time-out it never spins again (the launch still terminates)
+        auto timed_out = [&]() {
+            if (++spins <= limit) return false;
+            if (lane == 0) __hip_atomic_fetch_or(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dead = true;
+            return true;
+        };
+        for (int m0 = first; m0 < C; m0 += kKsChunk * stride) {
+            unsigned long long g0[kKsChunk];
+            // probe: granule 0 of every member of the chunk
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < kKsChunk; ++i)
+                    if (m0 + i * stride < C) g0[i] = ld_sc1_u64(p + (size_t)(m0 + i * stride) * src_stride);
+#pragma unroll
+                for (int i = 0; i < kKsChunk; ++i)
+                    if (m0 + i * stride < C) ok &= (unsigned)g0[i] == epoch;
+                if (__all(ok) || dead || timed_out()) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            // sweep, four members at a time: the other three granules (granule 0 matched above)
+#pragma unroll
+            for (int j0 = 0; j0 < kKsChunk; j0 += 4) {
+                if (m0 + j0 * stride >= C) break;
+                unsigned long long g[4][3];
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int src = m0 + (j0 + j) * stride;
+                        if (src < C) {
+                            const float* q = p + (size_t)src * src_stride;
+                            g[j][0] = ld_sc1_u64(q + 2);
+                            g[j][1] = ld_sc1_u64(q + 256);
+                            g[j][2] = ld_sc1_u64(q + 258);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (m0 + (j0 + j) * stride < C)
+                            ok &= (unsigned)g[j][0] == epoch && (unsigned)g[j][1] == epoch && (unsigned)g[j][2] == epoch;
+                    if (__all(ok) || dead || timed_out()) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (m0 + (j0 + j) * stride < C)
+                        s += floatx4{__uint_as_float((unsigned)(g0[j0 + j] >> 32)), __uint_as_float((unsigned)(g[j][0] >> 32)),
+                                     __uint_as_float((unsigned)(g[j][1] >> 32)), __uint_as_float((unsigned)(g[j][2] >> 32))};
+            }
+        }
+        return s;
+    }
+}
+// one hand-off: R1 publishes and waits; R2 has nothing to do here (ks_reduce polls)
+template <bool GR>
+__device__ __forceinline__ void ks_handoff(unsigned* flags, int c, int C, unsigned epoch, unsigned* err, unsigned limit,
+                                           unsigned code) {
+    if constexpr (!GR) {
+        publish(flags + c, epoch);
+        wait_all(flags, C, epoch, err, limit, code);
+    }
 }
 __device__ __forceinline__ floatx4 mfma4(floatx4 a, floatx4 b, floatx4 acc) {
 #pragma unroll
@@ -78,14 +186,17 @@ __device__ __forceinline__ floatx4 ks_frag(const float* w, int nb, int Kb, int k
     return ok ? reinterpret_cast<const floatx4*>(w)[((size_t)nb * Kb + kb) * 64 + lane] : floatx4{0.f, 0.f, 0.f, 0.f};
 }
 
-// exchange buffers of one tile and parity (floats)
+// exchange buffers of one tile (floats); R1 keeps two copies (step parity), R2 one (see above)
 struct KsBuf {
     size_t g, q, s, total;
-    __host__ __device__ explicit KsBuf(int C) {
+    int copies;
+    __host__ __device__ KsBuf(int C, bool gr) {
+        const size_t img = gr ? 512 : 256;
         g = 0;
-        q = g + (size_t)C * C * 4 * 256;     // [dest][src][4 accumulators][64 lanes x 4]
-        s = q + (size_t)C * C * 256;         // [dest][src][256]
-        total = s + (size_t)C * 8 * 256;     // [src][<= 8 (block, mean | raw) pairs][256]
+        q = g + (size_t)C * C * 4 * img;     // [dest][src][4 accumulators][image]
+        s = q + (size_t)C * C * img;         // [dest][src][image]
+        total = s + (size_t)C * 8 * img;     // [src][<= 8 (block, mean | raw) pairs][image]
+        copies = gr ? 1 : 2;
     }
 };
 
@@ -119,8 +230,10 @@ __device__ __forceinline__ void ks_put4(float* p, floatx4 v, int n_valid) {
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
+template <bool GR>
 __global__ __launch_bounds__(kThreads) void observe_kfwd_kernel(bd_observe_fwd_args a_, float* __restrict__ ws, int C, int tiles,
                                                                 unsigned spin_limit) {
+    constexpr int IMG = KsImg<GR>::floats;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     BD_KARGS(bd_observe_fwd_args, ap);
 #define a (*ap)
@@ -132,13 +245,13 @@ __global__ __launch_bounds__(kThreads) void observe_kfwd_kernel(bd_observe_fwd_a
     float* sf = smem;                               // masked state, fragment tiles
     float* af = sf + Kb_s * kFragFloats;
     float* s_plain = af + Kb_a * kFragFloats;       // [16][S]
-    float* red = s_plain + ((16 * a.S + 3) & ~3);   // [8 waves][64][4]
-    float* plain = red + kWaves * 256;              // [2][16][Np]
+    float* red = s_plain + ((16 * a.S + 3) & ~3);   // [2][8 waves][64][4]: the two reductions of a step alternate
+    float* plain = red + 2 * kWaves * 256;          // [parts][2][16][Np]: head sums, one copy per helper wave group
 
     unsigned* flags = reinterpret_cast<unsigned*>(ws) + tile * kMaxCluster;
     unsigned* err = reinterpret_cast<unsigned*>(ws) + tiles * kMaxCluster;
-    const KsBuf kb_(C);
-    float* xbase = ws + cluster_ws_header_floats(tiles) + (size_t)tile * 2 * kb_.total;
+    const KsBuf kb_(C, GR);
+    float* xbase = ws + cluster_ws_header_floats(tiles) + (size_t)tile * kb_.copies * kb_.total;
 
     // ---- resident weight slices (K block c of every layer) ----
     floatx4 we_s[kKsMaxS], we_a[kKsMaxA];           // embed: output block c
@@ -156,8 +269,12 @@ __global__ __launch_bounds__(kThreads) void observe_kfwd_kernel(bd_observe_fwd_a
         wg[i][4] = ks_frag(a.w_hz, nbo, Kb_h, c, lane, ok); wg[i][5] = ks_frag(a.w_hn, nbo, Kb_h, c, lane, ok);
         wq[i] = ks_frag(a.w_q1h, nbo, Kb_h, c, lane, nbo < Kb_hd);
     }
-    const int pair_nb = wave >> 1, pair_raw = wave & 1;              // head pair of this wave: (state block, mean | raw)
-    const bool has_pair = pair_nb < Kb_s;
+    // head pairs (state block, mean | raw): wave w works on pair w % npairs; the waves with part = w / npairs == 0 form the
+    // partial products, and all nparts groups share the sum over the members (group `part` takes members part, part + nparts, ..)
+    const int npairs = 2 * Kb_s, nparts = kWaves / npairs;
+    const int pair = wave % npairs, part = wave / npairs;
+    const int pair_nb = pair >> 1, pair_raw = pair & 1;
+    const bool has_pair = part == 0, sums_pair = part < nparts;
     const floatx4 wh = ks_frag(pair_raw ? a.w_q2s : a.w_q2m, pair_nb, Kb_hd, c, lane, has_pair && c < Kb_hd);
     // this lane's elements: row frow, columns fcol0 .. fcol0 + 3 of block c
     const int frow = lane & 15, fcol0 = c * 16 + 4 * (lane >> 4);
@@ -196,30 +313,47 @@ __global__ __launch_bounds__(kThreads) void observe_kfwd_kernel(bd_observe_fwd_a
 
     const bool lead = (c == 0);
     floatx4* __restrict__ RED4 = reinterpret_cast<floatx4*>(red);
+    floatx4* __restrict__ REDB = RED4 + kWaves * 64;
     const floatx4 z4 = floatx4{0.f, 0.f, 0.f, 0.f};
+    bool dead = false;
+
+    // this thread's first elements of phase A (nonterminal flag of its state element, its action element): requested one step
+    // ahead, so that a step does not start behind an HBM round trip
+    auto load_nt = [&](int t, int i) {
+        const int r = i / (Kb_s * 16), k = i - r * (Kb_s * 16);
+        return (a.nonterm && i < 16 * Kb_s * 16 && row0 + r < a.B && k < a.S) ? a.nonterm[(size_t)t * a.B + row0 + r] : 1.f;
+    };
+    auto load_ac = [&](int t, int i) {
+        const int r = i / (Kb_a * 16), k = i - r * (Kb_a * 16);
+        return (i < 16 * Kb_a * 16 && row0 + r < a.B && k < a.A) ? a.actions[((size_t)t * a.B + row0 + r) * a.A + k] : 0.f;
+    };
+    float n_nt = load_nt(0, (int)threadIdx.x), n_ac = load_ac(0, (int)threadIdx.x);
 
     for (int t = 0; t < a.T; ++t) {
         const size_t tb = (size_t)t * a.B;
         const int tid = bd_tid();
-        float* xb = xbase + (size_t)(t & 1) * kb_.total;
+        float* xb = xbase + (size_t)(GR ? 0 : (t & 1)) * kb_.total;
         BD_KSTAMP(0);
         BD_KARGS_FRESH(ap);
+        const float c_nt = n_nt, c_ac = n_ac;
+        if (t + 1 < a.T) {
+            n_nt = load_nt(t + 1, tid);
+            n_ac = load_ac(t + 1, tid);
+        }
         // ---- A: masked state / action fragments (every member; K of the embed layer is tiny) ----
         for (int i = tid; i < 16 * Kb_s * 16; i += blockDim.x) {
             const int r = i / (Kb_s * 16), k = i - r * (Kb_s * 16);
             const int gr = row0 + r;
             float v = 0.f;
             if (gr < a.B && k < a.S) {
-                v = s_plain[r * a.S + k];
-                if (a.nonterm) v *= a.nonterm[tb + gr];
+                v = s_plain[r * a.S + k] * (i == tid ? c_nt : load_nt(t, i));
                 if (lead && a.sv_s) a.sv_s[(tb + gr) * a.S + k] = v;
             }
             sf[frag_idx(r, k)] = v;
         }
         for (int i = tid; i < 16 * Kb_a * 16; i += blockDim.x) {
             const int r = i / (Kb_a * 16), k = i - r * (Kb_a * 16);
-            const int gr = row0 + r;
-            af[frag_idx(r, k)] = (gr < a.B && k < a.A) ? a.actions[(tb + gr) * a.A + k] : 0.f;
+            af[frag_idx(r, k)] = i == tid ? c_ac : load_ac(t, i);
         }
         // operands of the later epilogues: requested now, consumed after the hand-offs
         const floatx4 pre4 = rok ? ks_row4(a.pre_emb + (tb + grow) * a.Hd + fcol0, nhd) : z4;
@@ -258,18 +392,20 @@ __global__ __launch_bounds__(kThreads) void observe_kfwd_kernel(bd_observe_fwd_a
                 R = mfmaT(wg[i][3], h4, R);
                 Z = mfmaT(wg[i][4], h4, Z);
                 const floatx4 NH = mfmaT(wg[i][5], h4, z4);
-                float* dst = xb + kb_.g + ((size_t)(nbo * C + c) * 4) * 256 + lane * 4;
-                ks_store4(dst, R); ks_store4(dst + 256, Z); ks_store4(dst + 512, NI); ks_store4(dst + 768, NH);
+                float* dst = xb + kb_.g + ((size_t)(nbo * C + c) * 4) * IMG;
+                const unsigned ep = (unsigned)(3 * t + 1);
+                ks_emit<GR>(dst, lane, R, ep); ks_emit<GR>(dst + IMG, lane, Z, ep);
+                ks_emit<GR>(dst + 2 * IMG, lane, NI, ep); ks_emit<GR>(dst + 3 * IMG, lane, NH, ep);
             }
         }
-        publish(flags + c, (unsigned)(3 * t + 1));
         BD_KSTAMP(3);
-        wait_all(flags, C, (unsigned)(3 * t + 1), err, spin_limit, kErrFwd);
+        ks_handoff<GR>(flags, c, C, (unsigned)(3 * t + 1), err, spin_limit, kErrFwd);
         BD_KSTAMP(4);
         // ---- F3: sum the C partials of block c (wave = (gate, half of the members)); every wave finishes the GRU gates ----
         {
             const int g = wave & 3, half = wave >> 2;
-            RED4[wave * 64 + lane] = ks_sum(xb + kb_.g + ((size_t)(c * C) * 4 + g) * 256, (size_t)4 * 256, half, 2, C, lane);
+            RED4[wave * 64 + lane] = ks_reduce<GR>(xb + kb_.g + ((size_t)(c * C) * 4 + g) * IMG, (size_t)4 * IMG, half, 2, C, lane,
+                                                   (unsigned)(3 * t + 1), err, spin_limit, kErrFwd, dead);
         }
         lds_barrier();
         {
@@ -297,34 +433,36 @@ __global__ __launch_bounds__(kThreads) void observe_kfwd_kernel(bd_observe_fwd_a
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int nbo = wave + kWaves * i;
-            if (nbo < Kb_hd) ks_store4(xb + kb_.q + (size_t)(nbo * C + c) * 256 + lane * 4, mfmaT(wq[i], h4, z4));
+            if (nbo < Kb_hd) ks_emit<GR>(xb + kb_.q + (size_t)(nbo * C + c) * IMG, lane, mfmaT(wq[i], h4, z4), (unsigned)(3 * t + 2));
         }
-        publish(flags + c, (unsigned)(3 * t + 2));       // (its barrier also orders the RED reads above before the next writes)
         BD_KSTAMP(6);
-        wait_all(flags, C, (unsigned)(3 * t + 2), err, spin_limit, kErrFwd);
+        ks_handoff<GR>(flags, c, C, (unsigned)(3 * t + 2), err, spin_limit, kErrFwd);
         BD_KSTAMP(7);
-        // ---- F5: q_c = ELU(sum + pre_emb_c + b): every wave ----
-        RED4[wave * 64 + lane] = c < Kb_hd ? ks_sum(xb + kb_.q + (size_t)(c * C) * 256, 256, wave, kWaves, C, lane) : z4;
+        // ---- F5: q_c = ELU(sum + pre_emb_c + b): every wave (second RED buffer: a slow wave may still read the first) ----
+        REDB[wave * 64 + lane] = c < Kb_hd ? ks_reduce<GR>(xb + kb_.q + (size_t)(c * C) * IMG, IMG, wave, kWaves, C, lane,
+                                                          (unsigned)(3 * t + 2), err, spin_limit, kErrFwd, dead) : z4;
         lds_barrier();
         floatx4 q4 = bq4 + pre4;
-        for (int w = 0; w < kWaves; ++w) q4 += RED4[w * 64 + lane];
+        for (int w = 0; w < kWaves; ++w) q4 += REDB[w * 64 + lane];
 #pragma unroll
         for (int i = 0; i < 4; ++i) q4[i] = (rok && i < nhd) ? elu(q4[i]) : 0.f;
         if (wave == 0 && rok && a.sv_q) ks_put4(a.sv_q + (tb + grow) * a.Hd + fcol0, q4, nhd);
         BD_KSTAMP(8);
         BD_KARGS_FRESH(ap);
         // ---- F6: (mean, raw) partials over K block c; all-reduce ----
-        if (has_pair) ks_store4(xb + kb_.s + (size_t)(c * 8 + wave) * 256 + lane * 4, mfmaT(wh, q4, z4));
-        publish(flags + c, (unsigned)(3 * t + 3));
+        if (has_pair) ks_emit<GR>(xb + kb_.s + (size_t)(c * 8 + pair) * IMG, lane, mfmaT(wh, q4, z4), (unsigned)(3 * t + 3));
         BD_KSTAMP(9);
-        wait_all(flags, C, (unsigned)(3 * t + 3), err, spin_limit, kErrFwd);
+        ks_handoff<GR>(flags, c, C, (unsigned)(3 * t + 3), err, spin_limit, kErrFwd);
         BD_KSTAMP(10);
         BD_KARGS_FRESH(ap);
-        // ---- F7: every member sums the head partials, then samples s' elementwise ----
-        if (has_pair) {
-            const floatx4 v = ks_sum(xb + kb_.s + (size_t)wave * 256, (size_t)8 * 256, 0, 1, C, lane) + bh4;
+        // ---- F7: every member sums the head partials (wave group `part` its share of the members), then samples s' ----
+        if (sums_pair) {
+            floatx4 v = ks_reduce<GR>(xb + kb_.s + (size_t)pair * IMG, (size_t)8 * IMG, part, nparts, C, lane, (unsigned)(3 * t + 3), err,
+                                      spin_limit, kErrFwd, dead);
+            if (part == 0) v += bh4;
+            float* pl = plain + (size_t)part * 2 * 16 * Np;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) plain[pair_raw * 16 * Np + frow * Np + pair_nb * 16 + 4 * (lane >> 4) + i] = v[i];
+            for (int i = 0; i < 4; ++i) pl[pair_raw * 16 * Np + frow * Np + pair_nb * 16 + 4 * (lane >> 4) + i] = v[i];
         }
         lds_barrier();
         for (int e = tid; e < 16 * a.S; e += blockDim.x) {
@@ -332,7 +470,11 @@ __global__ __launch_bounds__(kThreads) void observe_kfwd_kernel(bd_observe_fwd_a
             const int gr = row0 + row;
             float st = 0.f;
             if (gr < a.B) {
-                const float Mn = plain[row * Np + col], Rw = plain[16 * Np + row * Np + col];
+                float Mn = plain[row * Np + col], Rw = plain[16 * Np + row * Np + col];
+                for (int pt = 1; pt < nparts; ++pt) {
+                    Mn += plain[pt * 2 * 16 * Np + row * Np + col];
+                    Rw += plain[pt * 2 * 16 * Np + 16 * Np + row * Np + col];
+                }
                 const float ee = e == tid ? eps : a.eps_post[(tb + gr) * a.S + col];
                 const float sd = softplusf(Rw) + a.min_std;
                 st = Mn + sd * ee;
@@ -352,8 +494,10 @@ __global__ __launch_bounds__(kThreads) void observe_kfwd_kernel(bd_observe_fwd_a
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------------
+template <bool GR>
 __global__ __launch_bounds__(kThreads) void observe_kbwd_kernel(bd_observe_bwd_args a_, float* __restrict__ ws, int C, int tiles,
                                                                 unsigned spin_limit) {
+    constexpr int IMG = KsImg<GR>::floats;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     BD_KARGS(bd_observe_bwd_args, ap);
 #define a (*ap)
@@ -364,13 +508,15 @@ __global__ __launch_bounds__(kThreads) void observe_kbwd_kernel(bd_observe_bwd_a
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float* dM = smem;                               // Kb_s fragment tiles
     float* dRaw = dM + Kb_s * kFragFloats;
-    float* ds_plain = dRaw + Kb_s * kFragFloats;    // [16][S]
-    float* red = ds_plain + ((16 * a.S + 3) & ~3);  // [8 waves][64][4]
+    float* ds_plain = dRaw + Kb_s * kFragFloats;    // [parts][16][S]: d state of the next step, one partial sum per wave group
+    const int nparts = kWaves / Kb_s;               // wave w: state block w % Kb_s, members part = w / Kb_s, part + nparts, ...
+    const int dsp_stride = (16 * a.S + 3) & ~3;
+    float* red = ds_plain + (size_t)nparts * dsp_stride;   // [2][8 waves][64][4]
 
     unsigned* flags = reinterpret_cast<unsigned*>(ws) + tile * kMaxCluster;
     unsigned* err = reinterpret_cast<unsigned*>(ws) + tiles * kMaxCluster;
-    const KsBuf kb_(C);                             // backward uses: g as [dest][src][2][256] (DX, DH), q as [dest][src][256] (dh),
-    float* xbase = ws + cluster_ws_header_floats(tiles) + (size_t)tile * 2 * kb_.total;      //   s as [src][Kb_s][256] (ds)
+    const KsBuf kb_(C, GR);                         // backward uses: g as [dest][src][2][image] (DX, DH), q as [dest][src][image] (dh),
+    float* xbase = ws + cluster_ws_header_floats(tiles) + (size_t)tile * kb_.copies * kb_.total;   // s as [src][Kb_s][image] (ds)
 
     // ---- resident weight slices ----
     floatx4 w2m[kKsMaxS], w2s[kKsMaxS];             // dQ block c: wt_q2m / wt_q2s (out = Hd, in = S)
@@ -389,39 +535,98 @@ __global__ __launch_bounds__(kThreads) void observe_kbwd_kernel(bd_observe_bwd_a
         wg[i][2] = ks_frag(a.wt_in, nbo, Kb_h, c, lane, ok); wg[i][3] = ks_frag(a.wt_hr, nbo, Kb_h, c, lane, ok);
         wg[i][4] = ks_frag(a.wt_hz, nbo, Kb_h, c, lane, ok); wg[i][5] = ks_frag(a.wt_hn, nbo, Kb_h, c, lane, ok);
     }
-    const floatx4 wes = ks_frag(a.wt_embed_s, wave, Kb_h, c, lane, wave < Kb_s);  // (out = S, in = Be): state block `wave`
+    const int sblk = wave % Kb_s, spart = wave / Kb_s;
+    const floatx4 wes = ks_frag(a.wt_embed_s, sblk, Kb_h, c, lane, spart == 0);  // (out = S, in = Be): state block of this wave
     const int frow = lane & 15, fcol0 = c * 16 + 4 * (lane >> 4);
     const int grow = row0 + frow;
     const int nbe = a.Be - fcol0 < 0 ? 0 : (a.Be - fcol0 < 4 ? a.Be - fcol0 : 4);
     const int nhd = a.Hd - fcol0 < 0 ? 0 : (a.Hd - fcol0 < 4 ? a.Hd - fcol0 : 4);
     const bool rok = grow < a.B;
 
-    for (int i = threadIdx.x; i < 16 * a.S; i += blockDim.x) ds_plain[i] = 0.f;
+    for (int i = threadIdx.x; i < nparts * dsp_stride; i += blockDim.x) ds_plain[i] = 0.f;
     lds_barrier();
 
     const bool lead = (c == 0);
     floatx4* __restrict__ RED4 = reinterpret_cast<floatx4*>(red);
+    floatx4* __restrict__ REDB = RED4 + kWaves * 64;
     const floatx4 z4 = floatx4{0.f, 0.f, 0.f, 0.f};
     floatx4 dhc4 = z4;                               // belief-gradient carry of block c (every wave holds a copy)
     unsigned epoch = 0;
+    bool dead = false;
+
+    // Operands that do not depend on the recurrence (saved activations, incoming gradients, noise) are requested ONE STEP AHEAD:
+    // a step starts with them in registers instead of behind an HBM round trip (B1 was 6.4k of 32.9k cycles, tools/ks_stamps.py).
+    struct B1v { float dfs, dpm, eps, dps, pstd; };
+    struct Svv { floatx4 svq4, svx4, gr4, gz4, gn4, gh4, hp4, dft4; };
+    auto load_b1 = [&](int t, int i) {
+        B1v v{0.f, 0.f, 0.f, 0.f, 0.f};
+        const int r = i / (Kb_s * 16), k = i - r * (Kb_s * 16);
+        const int gr = row0 + r;
+        if (i < 16 * Kb_s * 16 && gr < a.B && k < a.S) {
+            const size_t tb = (size_t)t * a.B, idx = (tb + gr) * a.S + k;
+            v.dfs = a.dfeat[(tb + gr) * F + a.Be + k];
+            v.dpm = a.dpost_mean ? a.dpost_mean[idx] : 0.f;
+            v.eps = a.eps_post[idx];
+            v.dps = a.dpost_std ? a.dpost_std[idx] : 0.f;
+            v.pstd = a.post_std[idx];
+        }
+        return v;
+    };
+    auto load_sv = [&](int t) {
+        Svv v;
+        v.svq4 = floatx4{1.f, 1.f, 1.f, 1.f};
+        v.svx4 = v.svq4;
+        v.gr4 = v.gz4 = v.gn4 = v.gh4 = v.hp4 = v.dft4 = z4;
+        if (rok) {
+            const size_t tb = (size_t)t * a.B;
+            v.svq4 = ks_row4(a.sv_q + (tb + grow) * a.Hd + fcol0, nhd);
+            v.svx4 = ks_row4(a.sv_x + (tb + grow) * a.Be + fcol0, nbe);
+            const float* gg = a.sv_gates + (tb + grow) * 4 * a.Be + fcol0;
+            v.gr4 = ks_row4(gg, nbe); v.gz4 = ks_row4(gg + a.Be, nbe); v.gn4 = ks_row4(gg + 2 * a.Be, nbe); v.gh4 = ks_row4(gg + 3 * a.Be, nbe);
+            v.hp4 = t > 0 ? ks_row4(a.feat + (tb - a.B + grow) * F + fcol0, nbe) : ks_row4(a.init_belief + (size_t)grow * a.Be + fcol0, nbe);
+            v.dft4 = ks_row4(a.dfeat + (tb + grow) * F + fcol0, nbe);
+        }
+        return v;
+    };
+    constexpr bool AHEAD = !GR;          // (the granule form has no registers to spare: it loads at the top of the step)
+    B1v nb1{0.f, 0.f, 0.f, 0.f, 0.f};
+    Svv nsv{z4, z4, z4, z4, z4, z4, z4, z4};
+    if constexpr (AHEAD) {
+        nb1 = load_b1(a.T - 1, (int)threadIdx.x);
+        nsv = load_sv(a.T - 1);
+    }
 
     for (int t = a.T - 1; t >= 0; --t) {
         const size_t tb = (size_t)t * a.B;
         const int tid = bd_tid();
-        float* xb = xbase + (size_t)(t & 1) * kb_.total;
+        float* xb = xbase + (size_t)(GR ? 0 : (t & 1)) * kb_.total;
         BD_KSTAMP(16);
         BD_KARGS_FRESH(ap);
+        B1v cb1;
+        Svv sv;
+        if constexpr (AHEAD) {
+            cb1 = nb1;
+            sv = nsv;
+            if (t > 0) {
+                nb1 = load_b1(t - 1, tid);
+                nsv = load_sv(t - 1);
+            }
+        } else {
+            cb1 = load_b1(t, tid);
+            sv = load_sv(t);
+        }
         // ---- B1: through the sample / softplus into (mean, raw) (every member, elementwise) ----
         for (int i = tid; i < 16 * Kb_s * 16; i += blockDim.x) {
             const int r = i / (Kb_s * 16), k = i - r * (Kb_s * 16);
             const int gr = row0 + r;
             float dm = 0.f, dr = 0.f;
             if (gr < a.B && k < a.S) {
-                const size_t idx = (tb + gr) * a.S + k;
-                const float dst = ds_plain[r * a.S + k] + a.dfeat[(tb + gr) * F + a.Be + k];
-                dm = dst + (a.dpost_mean ? a.dpost_mean[idx] : 0.f);
-                const float dsd = dst * a.eps_post[idx] + (a.dpost_std ? a.dpost_std[idx] : 0.f);
-                dr = dsd * one_minus_exp_neg(a.post_std[idx] - a.min_std);
+                const B1v v = i == tid ? cb1 : load_b1(t, i);
+                float dst = v.dfs;
+                for (int pt = 0; pt < nparts; ++pt) dst += ds_plain[pt * dsp_stride + r * a.S + k];
+                dm = dst + v.dpm;
+                const float dsd = dst * v.eps + v.dps;
+                dr = dsd * one_minus_exp_neg(v.pstd - a.min_std);
                 if (lead) {
                     a.d_q2_out[(tb + gr) * 2 * a.S + k] = dm;
                     a.d_q2_out[(tb + gr) * 2 * a.S + a.S + k] = dr;
@@ -430,16 +635,7 @@ __global__ __launch_bounds__(kThreads) void observe_kbwd_kernel(bd_observe_bwd_a
             dM[frag_idx(r, k)] = dm;
             dRaw[frag_idx(r, k)] = dr;
         }
-        // saved operands of this lane's elements (every wave keeps its own copy): requested now
-        floatx4 svq4 = floatx4{1.f, 1.f, 1.f, 1.f}, svx4 = svq4, gr4 = z4, gz4 = z4, gn4 = z4, gh4 = z4, hp4 = z4, dft4 = z4;
-        if (rok) {
-            svq4 = ks_row4(a.sv_q + (tb + grow) * a.Hd + fcol0, nhd);
-            svx4 = ks_row4(a.sv_x + (tb + grow) * a.Be + fcol0, nbe);
-            const float* gg = a.sv_gates + (tb + grow) * 4 * a.Be + fcol0;
-            gr4 = ks_row4(gg, nbe); gz4 = ks_row4(gg + a.Be, nbe); gn4 = ks_row4(gg + 2 * a.Be, nbe); gh4 = ks_row4(gg + 3 * a.Be, nbe);
-            hp4 = t > 0 ? ks_row4(a.feat + (tb - a.B + grow) * F + fcol0, nbe) : ks_row4(a.init_belief + (size_t)grow * a.Be + fcol0, nbe);
-            dft4 = ks_row4(a.dfeat + (tb + grow) * F + fcol0, nbe);
-        }
+        const floatx4 svq4 = sv.svq4, svx4 = sv.svx4, gr4 = sv.gr4, gz4 = sv.gz4, gn4 = sv.gn4, gh4 = sv.gh4, hp4 = sv.hp4, dft4 = sv.dft4;
         lds_barrier();
         BD_KSTAMP(17);
         // ---- B2: dQ block c = ([dm | draw] W_q2)[:, block c] * ELU'(q_c): every wave, in registers ----
@@ -465,14 +661,13 @@ __global__ __launch_bounds__(kThreads) void observe_kbwd_kernel(bd_observe_bwd_a
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int nbo = wave + kWaves * i;
-            if (nbo < Kb_h) ks_store4(xb + kb_.q + (size_t)(nbo * C + c) * 256 + lane * 4, mfmaT(w1[i], dq4, z4));
+            if (nbo < Kb_h) ks_emit<GR>(xb + kb_.q + (size_t)(nbo * C + c) * IMG, lane, mfmaT(w1[i], dq4, z4), epoch);
         }
-        publish(flags + c, epoch);
         BD_KSTAMP(19);
-        wait_all(flags, C, epoch, err, spin_limit, kErrBwd);
+        ks_handoff<GR>(flags, c, C, epoch, err, spin_limit, kErrBwd);
         BD_KSTAMP(20);
         // ---- B4: total d belief of block c, gate gradients: every wave ----
-        RED4[wave * 64 + lane] = ks_sum(xb + kb_.q + (size_t)(c * C) * 256, 256, wave, kWaves, C, lane);
+        RED4[wave * 64 + lane] = ks_reduce<GR>(xb + kb_.q + (size_t)(c * C) * IMG, IMG, wave, kWaves, C, lane, epoch, err, spin_limit, kErrBwd, dead);
         lds_barrier();
         floatx4 vr4, vz4, vni4, vnh4, carry4;
         {
@@ -509,24 +704,24 @@ __global__ __launch_bounds__(kThreads) void observe_kbwd_kernel(bd_observe_bwd_a
                 floatx4 DX = mfmaT(wg[i][0], vr4, z4), DH = mfmaT(wg[i][3], vr4, z4);
                 DX = mfmaT(wg[i][1], vz4, DX); DH = mfmaT(wg[i][4], vz4, DH);
                 DX = mfmaT(wg[i][2], vni4, DX); DH = mfmaT(wg[i][5], vnh4, DH);
-                float* dst = xb + kb_.g + ((size_t)(nbo * C + c) * 2) * 256 + lane * 4;
-                ks_store4(dst, DX); ks_store4(dst + 256, DH);
+                float* dst = xb + kb_.g + ((size_t)(nbo * C + c) * 2) * IMG;
+                ks_emit<GR>(dst, lane, DX, epoch); ks_emit<GR>(dst + IMG, lane, DH, epoch);
             }
         }
-        publish(flags + c, epoch);
         BD_KSTAMP(22);
-        wait_all(flags, C, epoch, err, spin_limit, kErrBwd);
+        ks_handoff<GR>(flags, c, C, epoch, err, spin_limit, kErrBwd);
         BD_KSTAMP(23);
         // ---- B6: d embed pre-activation of block c, the carry's W_hh^T term: every wave ----
         {
             const int g = wave & 1, quarter = wave >> 1;
-            RED4[wave * 64 + lane] = ks_sum(xb + kb_.g + ((size_t)(c * C) * 2 + g) * 256, (size_t)2 * 256, quarter, 4, C, lane);
+            REDB[wave * 64 + lane] = ks_reduce<GR>(xb + kb_.g + ((size_t)(c * C) * 2 + g) * IMG, (size_t)2 * IMG, quarter, 4, C, lane, epoch,
+                                                   err, spin_limit, kErrBwd, dead);
         }
         lds_barrier();
         floatx4 de4;
         {
             floatx4 DX = z4, DH = z4;
-            for (int qd = 0; qd < 4; ++qd) { DX += RED4[(2 * qd) * 64 + lane]; DH += RED4[(2 * qd + 1) * 64 + lane]; }
+            for (int qd = 0; qd < 4; ++qd) { DX += REDB[(2 * qd) * 64 + lane]; DH += REDB[(2 * qd + 1) * 64 + lane]; }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool ok = rok && i < nbe;
@@ -539,20 +734,20 @@ __global__ __launch_bounds__(kThreads) void observe_kbwd_kernel(bd_observe_bwd_a
         BD_KARGS_FRESH(ap);
         // ---- B7: d state partials over K block c; all-reduce ----
         ++epoch;
-        if (wave < Kb_s) ks_store4(xb + kb_.s + (size_t)(c * 8 + wave) * 256 + lane * 4, mfmaT(wes, de4, z4));
-        publish(flags + c, epoch);
+        if (spart == 0) ks_emit<GR>(xb + kb_.s + (size_t)(c * 8 + sblk) * IMG, lane, mfmaT(wes, de4, z4), epoch);
         BD_KSTAMP(25);
-        wait_all(flags, C, epoch, err, spin_limit, kErrBwd);
+        ks_handoff<GR>(flags, c, C, epoch, err, spin_limit, kErrBwd);
         BD_KSTAMP(26);
         BD_KARGS_FRESH(ap);
-        // ---- B8: d posterior_state_t (through the nonterminal mask of this step's input) ----
-        if (wave < Kb_s) {
-            const floatx4 v = ks_sum(xb + kb_.s + (size_t)wave * 256, (size_t)8 * 256, 0, 1, C, lane);
+        // ---- B8: d posterior_state_t (through the nonterminal mask of this step's input); wave group `spart` sums its members ----
+        if (spart < nparts) {
+            const floatx4 v = ks_reduce<GR>(xb + kb_.s + (size_t)sblk * IMG, (size_t)8 * IMG, spart, nparts, C, lane, epoch, err, spin_limit,
+                                            kErrBwd, dead);
             const float mk = rok ? (a.nonterm ? a.nonterm[tb + grow] : 1.f) : 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int col = wave * 16 + 4 * (lane >> 4) + i;
-                if (col < a.S) ds_plain[frow * a.S + col] = v[i] * mk;
+                const int col = sblk * 16 + 4 * (lane >> 4) + i;
+                if (col < a.S) ds_plain[spart * dsp_stride + frow * a.S + col] = v[i] * mk;
             }
         }
         lds_barrier();
@@ -561,45 +756,79 @@ __global__ __launch_bounds__(kThreads) void observe_kbwd_kernel(bd_observe_bwd_a
 #undef a
 }
 
-size_t ksplit_ws_floats_per_tile(int C) { return 2 * KsBuf(C).total; }
+size_t ksplit_ws_floats_per_tile(int C) {
+    const KsBuf r1(C, false), r2(C, true);
+    const size_t x = r1.copies * r1.total, y = r2.copies * r2.total;
+    return x > y ? x : y;
+}
 
-int& ksplit_mode() {               // -1: as the environment says (BD_OBS_KSPLIT=0 switches it off), 0: off, 1: on
-    static int m = -1;
+int& ksplit_mode() {               // -1: as the environment says, 0: off (round-1 cluster form), 1: K-split with R1 hand-offs,
+    static int m = -1;             //  2: K-split with granule (R2) hand-offs
     return m;
+}
+static int ksplit_form() {         // 0 / 1 / 2 as above, environment resolved (BD_OBS_KSPLIT, default 1)
+    static const char* e = getenv("BD_OBS_KSPLIT");
+    if (ksplit_mode() >= 0) return ksplit_mode();
+    if (e && e[0] >= '0' && e[0] <= '2') return e[0] - '0';
+    return 1;
 }
 
 bool ksplit_ok(int Be, int S, int A, int Hd, int C) {
-    static const char* e = getenv("BD_OBS_KSPLIT");
-    if (ksplit_mode() == 0 || (ksplit_mode() < 0 && e && e[0] == '0')) return false;
+    if (ksplit_form() == 0) return false;
     return C == cdiv(Be, 16) && C <= 2 * kWaves && cdiv(Hd, 16) <= C && cdiv(S, 16) <= kKsMaxS && cdiv(A, 16) <= kKsMaxA &&
            S <= kHeadMaxN && 16 * S <= kThreads && 2 * cdiv(S, 16) <= kWaves;
 }
 
 static size_t ks_lds_fwd(int S, int A) {
     const int Kb_s = cdiv(S, 16), Kb_a = cdiv(A, 16);
-    return ((size_t)(Kb_s + Kb_a) * kFragFloats + ((16 * S + 3) & ~3) + kWaves * 256 + 2 * 16 * Kb_s * 16) * sizeof(float);
+    const int nparts = kWaves / (2 * Kb_s);
+    return ((size_t)(Kb_s + Kb_a) * kFragFloats + ((16 * S + 3) & ~3) + 2 * kWaves * 256 + (size_t)nparts * 2 * 16 * Kb_s * 16) * sizeof(float);
 }
 static size_t ks_lds_bwd(int S) {
     const int Kb_s = cdiv(S, 16);
-    return ((size_t)2 * Kb_s * kFragFloats + ((16 * S + 3) & ~3) + kWaves * 256) * sizeof(float);
+    const int nparts = kWaves / Kb_s;
+    return ((size_t)2 * Kb_s * kFragFloats + (size_t)nparts * ((16 * S + 3) & ~3) + 2 * kWaves * 256) * sizeof(float);
 }
 
-int launch_observe_kfwd(const bd_observe_fwd_args* a, float* ws, int C, int tiles, hipStream_t stream) {
-    if (allow_big_lds(observe_kfwd_kernel)) return -1;
-    const size_t dyn = launch_lds(observe_kfwd_kernel, ks_lds_fwd(a->S, a->A), "bd_observe_forward_cluster");
+// zero what the form polls: the member flags (R1) or the whole exchange buffer, whose tags restart at 1 (R2)
+static int ks_reset(float* ws, int C, int tiles, bool gr, hipStream_t stream, const char* who) {
+    const size_t floats = gr ? cluster_ws_flag_floats(tiles) : cluster_ws_flag_floats(tiles);
+    if (hipMemsetAsync(ws, 0, floats * sizeof(float), stream) != hipSuccess) return fail("%s: memset failed", who);
+    if (gr) {
+        const KsBuf kb(C, true);
+        float* x = ws + cluster_ws_header_floats(tiles);
+        if (hipMemsetAsync(x, 0, (size_t)tiles * kb.copies * kb.total * sizeof(float), stream) != hipSuccess)
+            return fail("%s: memset failed", who);
+    }
+    return 0;
+}
+
+template <bool GR>
+static int launch_kfwd(const bd_observe_fwd_args* a, float* ws, int C, int tiles, hipStream_t stream) {
+    if (allow_big_lds(observe_kfwd_kernel<GR>)) return -1;
+    const size_t dyn = launch_lds(observe_kfwd_kernel<GR>, ks_lds_fwd(a->S, a->A), "bd_observe_forward_cluster");
     if (!dyn) return -1;
-    hipLaunchKernelGGL(observe_kfwd_kernel, dim3(tiles * C), dim3(kThreads), dyn, stream, *a, ws, C, tiles, cluster_spin_limit());
+    if (ks_reset(ws, C, tiles, GR, stream, "bd_observe_forward_cluster")) return -1;
+    hipLaunchKernelGGL(observe_kfwd_kernel<GR>, dim3(tiles * C), dim3(kThreads), dyn, stream, *a, ws, C, tiles, cluster_spin_limit());
     BD_CHECK_LAUNCH("bd_observe_forward_cluster");
     return 0;
 }
-
-int launch_observe_kbwd(const bd_observe_bwd_args* a, float* ws, int C, int tiles, hipStream_t stream) {
-    if (allow_big_lds(observe_kbwd_kernel)) return -1;
-    const size_t dyn = launch_lds(observe_kbwd_kernel, ks_lds_bwd(a->S), "bd_observe_backward_cluster");
+template <bool GR>
+static int launch_kbwd(const bd_observe_bwd_args* a, float* ws, int C, int tiles, hipStream_t stream) {
+    if (allow_big_lds(observe_kbwd_kernel<GR>)) return -1;
+    const size_t dyn = launch_lds(observe_kbwd_kernel<GR>, ks_lds_bwd(a->S), "bd_observe_backward_cluster");
     if (!dyn) return -1;
-    hipLaunchKernelGGL(observe_kbwd_kernel, dim3(tiles * C), dim3(kThreads), dyn, stream, *a, ws, C, tiles, cluster_spin_limit());
+    if (ks_reset(ws, C, tiles, GR, stream, "bd_observe_backward_cluster")) return -1;
+    hipLaunchKernelGGL(observe_kbwd_kernel<GR>, dim3(tiles * C), dim3(kThreads), dyn, stream, *a, ws, C, tiles, cluster_spin_limit());
     BD_CHECK_LAUNCH("bd_observe_backward_cluster");
     return 0;
+}
+
+int launch_observe_kfwd(const bd_observe_fwd_args* a, float* ws, int C, int tiles, hipStream_t stream) {
+    return ksplit_form() == 2 ? launch_kfwd<true>(a, ws, C, tiles, stream) : launch_kfwd<false>(a, ws, C, tiles, stream);
+}
+int launch_observe_kbwd(const bd_observe_bwd_args* a, float* ws, int C, int tiles, hipStream_t stream) {
+    return ksplit_form() == 2 ? launch_kbwd<true>(a, ws, C, tiles, stream) : launch_kbwd<false>(a, ws, C, tiles, stream);
 }
 
 }  // namespace bd

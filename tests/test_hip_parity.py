@@ -98,6 +98,9 @@ def test_forward_pieces_vs_oracle(name):
                                           ("tiny_freenats0", False), ("config2", False),
                                           # the round-1 cluster form (GRU columns split, one all-gather per step)
                                           ("small", "round1"), ("tiny_freenats0", "round1"), ("config2", "round1"),
+                                          # the K-split form with granule ("the data is the flag") hand-offs
+                                          ("small", "ksplit_gr"), ("tiny_freenats0", "ksplit_gr"), ("config1", "ksplit_gr"),
+                                          ("config2", "ksplit_gr"),
                                           ("tiny_pixel", True), ("tiny_pixel_lin", True),
                                           ("tiny_pixel", "miopen"), ("tiny_pixel_lin", "miopen"),
                                           ("config3", True), ("tiny_discount", True), ("tiny_discount", False)])
@@ -109,10 +112,10 @@ def test_train_steps_vs_oracle_and_golden(name, cluster, monkeypatch):
     torch_convs = cluster == "miopen"
     if torch_convs:
         cluster = True
-    # cluster=True: the K-split cluster scan (csrc/observe_ksplit.hip, the default); "round1": observe_cluster.hip's form;
-    # False: one workgroup per tile (observe.hip)
-    cabi.check(cabi.lib.bd_observe_cluster_set_ksplit(0 if cluster == "round1" else -1))
-    if cluster == "round1":
+    # cluster=True: the K-split cluster scan (csrc/observe_ksplit.hip, the default: flag hand-offs); "ksplit_gr": the same scan
+    # with granule hand-offs; "round1": observe_cluster.hip's form; False: one workgroup per tile (observe.hip)
+    cabi.check(cabi.lib.bd_observe_cluster_set_ksplit({"round1": 0, "ksplit_gr": 2}.get(cluster, -1)))
+    if cluster in ("round1", "ksplit_gr"):
         cluster = True
     d, seed, hp, full, g, P, batch, noise, eng = _setup(name, cluster)
     if d.pixel:
