@@ -22,7 +22,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 BD_MAX_LAYERS = 6
-ACT_NONE, ACT_ELU = 0, 1
+ACT_NONE, ACT_ELU, ACT_ELU_GRAD = 0, 1, 2
 P = C.c_void_p
 F32 = C.c_float
 I32 = C.c_int
@@ -159,7 +159,7 @@ class ConvArgs(C.Structure):
                 ("nseg", I32), ("seglen", I32), ("C", I32), ("IH", I32), ("IW", I32), ("sy", I32), ("y0", I32),
                 ("ss", I32), ("sx", I32), ("x0", I32), ("mask", I32), ("cshift", I32), ("vec4", I32),
                 ("OH", I32), ("OW", I32), ("osy", I32), ("oy0", I32), ("osx", I32), ("ox0", I32), ("ldo", I32),
-                ("act", I32), ("fuse_cq", I32)]
+                ("act", I32), ("fuse_cq", I32), ("aux", P)]
 
 
 # every symbol include/bigdreamer_hip.h declares, with its signature
@@ -173,6 +173,9 @@ _SIGS = {
     "bd_mlp_set_tall": (I32, [I32]),
     "bd_wgrad_ws_floats": (C.c_size_t, [I32, I32, I32]),
     "bd_wgrad": (I32, [P, I32, P, I32, I32, I32, I32, P, I32, P, I32, P, C.c_size_t, P]),
+    "bd_wgrad_onehot_ok": (I32, [I32, I32]),
+    "bd_wgrad_onehot_ws_floats": (C.c_size_t, [I32, I32, I32, I32]),
+    "bd_wgrad_onehot": (I32, [P, I32, P, I32, P, I32, I32, I32, I32, P, I32, P, C.c_size_t, P]),
     "bd_wgrad_plan": (I32, [C.POINTER(WgradDesc), I32, C.POINTER(I32), C.POINTER(I32), C.POINTER(C.c_size_t)]),
     "bd_wgrad_grouped": (I32, [P, I32, I32, I32, P, P]),
     "bd_wgrad_grouped_phase": (I32, [P, I32, I32, I32, P, I32, P]),
@@ -225,7 +228,7 @@ _SIGS = {
     "bd_replay_gather_pixels_rng": (I32, [P, P, I32, I32, I32, C.c_ulonglong, C.c_ulonglong, P, P]),
     "bd_reduce_ws_floats": (C.c_size_t, []),
     "bd_conv_gemm": (I32, [C.POINTER(ConvArgs), P]),
-    "bd_conv_thin_forward": (I32, [P, I32, I32, I32, I32, I32, P, I32, P, I32, P, P]),
+    "bd_conv_thin_forward": (I32, [P, I32, I32, I32, I32, I32, P, I32, P, I32, P, P, P]),
     "bd_conv_pack_class": (I32, [P, P, I32, I32, I32, I32, I32, I32, I32, P]),
     "bd_conv_pack_fused": (I32, [P, P, I32, I32, I32, P]),
     "bd_elu_backward": (I32, [P, P, C.c_size_t, P]),

@@ -34,9 +34,10 @@ def taps(k: int, parity: int) -> int:
 
 
 def pattern_f(inp: torch.Tensor, out: torch.Tensor, w_packed: torch.Tensor, bias, imgs: int, IH: int, IW: int, Cin: int,
-              k: int, N: int, act: int) -> None:
+              k: int, N: int, act: int, aux=None) -> None:
     """out (imgs, OH, OW, N) = conv_stride2_valid(inp (imgs, IH, IW, Cin)) with packed W[N][(ky, kx, ci)] (+bias, act).
-    Also the dgrad of a transposed convolution (inp = gradient of its output)."""
+    Also the dgrad of a transposed convolution (inp = gradient of its output); act = ACT_ELU_GRAD multiplies by ELU' of the
+    saved outputs `aux` (same shape as out): the ELU backward of the layer below in the same pass."""
     OH, OW = conv_out(IH, k), conv_out(IW, k)
     a = cabi.ConvArgs()
     a.in_, a.out, a.w, a.bias = ptr(inp), ptr(out), ptr(w_packed), ptr(bias)
@@ -46,17 +47,19 @@ def pattern_f(inp: torch.Tensor, out: torch.Tensor, w_packed: torch.Tensor, bias
     a.vec4 = int(Cin % 4 == 0)
     a.cshift = _log2(Cin)
     a.OH, a.OW, a.osy, a.oy0, a.osx, a.ox0, a.ldo = OH, OW, 1, 0, 1, 0, N
-    a.act = act
+    a.act, a.aux = act, ptr(aux)
+    assert act != cabi.ACT_ELU_GRAD or (aux is not None and aux.numel() == out.numel())
     cabi.check(lib.bd_conv_gemm(C.byref(a), cabi.stream()))
 
 
 def thin_f(inp: torch.Tensor, out: torch.Tensor, w_plain: torch.Tensor, bias, imgs: int, IH: int, IW: int, Cin: int, k: int,
-           act: int) -> None:
+           act: int, aux=None) -> None:
     """pattern_f for a THIN image (Cin <= 4) and 32 output channels: out (imgs, OH, OW, 32) from the PLAIN weight matrix
     [32][(ky, kx, c)] (a 2-D view of the stored parameter; bd_conv_thin_forward, csrc/conv.hip)."""
     assert w_plain.dim() == 2 and w_plain.shape[0] == 32 and w_plain.shape[1] == k * k * Cin and w_plain.stride(1) == 1
+    assert act != cabi.ACT_ELU_GRAD or (aux is not None and aux.numel() == out.numel())
     cabi.check(lib.bd_conv_thin_forward(ptr(inp), imgs, IH, IW, Cin, k, w_plain.data_ptr(), w_plain.stride(0), ptr(bias), act,
-                                        ptr(out), cabi.stream()))
+                                        ptr(aux), ptr(out), cabi.stream()))
 
 
 def pattern_t(inp: torch.Tensor, out: torch.Tensor, w_classes: List[torch.Tensor], bias, imgs: int, IH: int, IW: int,
@@ -83,7 +86,7 @@ def pattern_t(inp: torch.Tensor, out: torch.Tensor, w_classes: List[torch.Tensor
 
 
 def pattern_t_fused(inp: torch.Tensor, out: torch.Tensor, w_fused: torch.Tensor, bias, imgs: int, IH: int, IW: int, Cin: int,
-                    k: int, N: int, OH: int, OW: int, act: int) -> None:
+                    k: int, N: int, OH: int, OW: int, act: int, aux=None) -> None:
     """pattern_t with the four parity classes in ONE launch: they read the same T x T window (T = (k+1)//2), so their
     weights are the columns of one matrix (fused_pack) and the window is gathered once instead of four times."""
     assert Cin % 4 == 0 and Cin & (Cin - 1) == 0, "T pattern: channel count must be a power of two >= 4"
@@ -95,7 +98,8 @@ def pattern_t_fused(inp: torch.Tensor, out: torch.Tensor, w_fused: torch.Tensor,
     a.sy, a.y0, a.ss, a.sx, a.x0, a.mask = 1, 0, -1, 1, -(T - 1), 1
     a.vec4, a.cshift = 1, _log2(Cin)
     a.OH, a.OW, a.osy, a.oy0, a.osx, a.ox0, a.ldo = OH, OW, 2, 0, 2, 0, N
-    a.act, a.fuse_cq = act, N
+    a.act, a.fuse_cq, a.aux = act, N, ptr(aux)
+    assert act != cabi.ACT_ELU_GRAD or (aux is not None and aux.numel() == out.numel())
     cabi.check(lib.bd_conv_gemm(C.byref(a), cabi.stream()))
 
 

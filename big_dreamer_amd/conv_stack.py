@@ -24,6 +24,9 @@ import os
 lib = cabi.lib
 ptr = cabi.ptr
 THIN = os.environ.get("BD_CONV_THIN", "1") != "0"      # "0": the 3-channel-image layers on the row-tile gather kernels (A/B)
+# "1": the ELU backward as the epilogue of the dgrad kernels (BD_ACT_ELU_GRAD; parity-tested).  Off: measured 13.2 vs 13.1 ms
+# per step at configs[2] -- the scattered loads of the saved outputs cost the gather kernels more than the separate pass
+FUSE_ELU = os.environ.get("BD_CONV_FUSE_ELU", "0") != "0"
 
 ENC = [(3, 32, 4), (32, 64, 4), (64, 128, 4), (128, 256, 4)]          # (ci, co, k); input 64 -> 31 -> 14 -> 6 -> 2
 ENC_SIZES = [64, 31, 14, 6, 2]
@@ -162,13 +165,16 @@ class ConvStacks:
                    gather=(k, k * co, isz, isz, osz, osz, co))
             self._colsum(wb, g, M * osz * osz, co, G(name + ".bias"))
             # d input = strided conv of g with the stored matrix [ci][(ky, kx, co)], then through the ELU of the layer below
+            # (the ELU backward is the dgrad kernels' epilogue: BD_ACT_ELU_GRAD with the saved outputs a_in)
             gi = e.buf(f"cv_gd{j + 1}", M, isz, isz, ci)
             if j == 2 and THIN:         # dgrad of ConvT(32 -> 3): a k6 convolution of the 3-channel image gradient
                 conv.thin_f(g, gi, e.Ws("observation_model", f"decoder.{DEC_IDX[j]}.weight").view(ci, k * k * co), None, M, osz,
-                            osz, co, k, cabi.ACT_NONE)
+                            osz, co, k, cabi.ACT_ELU_GRAD if FUSE_ELU else cabi.ACT_NONE, a_in if FUSE_ELU else None)
             else:
-                conv.pattern_f(g, gi, self.pk_dec_f[j], None, M, osz, osz, co, k, ci, cabi.ACT_NONE)
-            cabi.check(lib.bd_elu_backward(ptr(gi), ptr(a_in), gi.numel(), cabi.stream()))
+                conv.pattern_f(g, gi, self.pk_dec_f[j], None, M, osz, osz, co, k, ci,
+                               cabi.ACT_ELU_GRAD if FUSE_ELU else cabi.ACT_NONE, a_in if FUSE_ELU else None)
+            if not FUSE_ELU:
+                cabi.check(lib.bd_elu_backward(ptr(gi), ptr(a_in), gi.numel(), cabi.stream()))
             g = gi
         # the 1x1 -> 5x5 layer as a Linear: dW[ci][(ky,kx,co)] = sum_m l0[m][ci] * g[m][(ky,kx,co)]
         l0 = self.acts_dec[0]
@@ -203,10 +209,12 @@ class ConvStacks:
         for i in (3, 2, 1, 0):
             ci, co, k = ENC[i]
             isz, osz = ENC_SIZES[i], ENC_SIZES[i + 1]
-            cabi.check(lib.bd_elu_backward(ptr(g), ptr(self.acts_enc[i + 1]), g.numel(), cabi.stream()))      # d pre-activation
+            if i == 3 or not FUSE_ELU:  # d pre-activation (below the top layer it is the epilogue of the dgrad that produced g)
+                cabi.check(lib.bd_elu_backward(ptr(g), ptr(self.acts_enc[i + 1]), g.numel(), cabi.stream()))
             wb.add(g, co, self.acts_enc[i], 0, M * osz * osz, co, k * k * ci, G(f"model.{2 * i}.weight"), k * k * ci,
                    G(f"model.{2 * i}.bias"), gather=(k, k * ci, osz, osz, isz, isz, ci))
             if i > 0:
                 gi = e.buf(f"cv_ga{i}", M, isz, isz, ci)
-                conv.pattern_t_fused(g, gi, self.pk_enc_t[i], None, M, osz, osz, co, k, ci, isz, isz, cabi.ACT_NONE)
+                conv.pattern_t_fused(g, gi, self.pk_enc_t[i], None, M, osz, osz, co, k, ci, isz, isz,
+                                     cabi.ACT_ELU_GRAD if FUSE_ELU else cabi.ACT_NONE, self.acts_enc[i] if FUSE_ELU else None)
                 g = gi

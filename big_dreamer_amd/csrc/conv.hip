@@ -29,17 +29,21 @@ struct ConvFrag {
 };
 
 // One segment: column block nb, row tiles rt0 .. rt0+RTC-1 of the LDS tile X[rt][Kb] (fragment order).
-template <int RTC, class Epi>
+// `pre(rt, nb)` returns the epilogue's per-element multipliers (BD_ACT_ELU_GRAD: ELU' from the saved output; 1 otherwise):
+// requested BEFORE the contraction, consumed after it.
+template <int RTC, class Epi, class Pre>
 __device__ __forceinline__ void conv_segment(const float* __restrict__ X, int Kb, const float* __restrict__ Wp,
-                                             const float* __restrict__ bias, int N, int bmod, int nb, int rt0, Epi&& epi) {
+                                             const float* __restrict__ bias, int N, int bmod, int nb, int rt0, Epi&& epi, Pre&& pre) {
     const int lane = bd_tid() & 63;
     const int col = nb * 16 + (lane & 15);
     const float b = (bias != nullptr && col < N) ? bias[bmod > 0 ? col % bmod : col] : 0.f;
     floatx4 acc[RTC], acc2[RTC];      // two chains per row tile: a lone dependent chain pays 40 cycles per 32-cycle MFMA
+    floatx4 mul[RTC];
 #pragma unroll
     for (int r = 0; r < RTC; ++r) {
         acc[r] = floatx4{b, b, b, b};
         acc2[r] = floatx4{0.f, 0.f, 0.f, 0.f};
+        mul[r] = pre(rt0 + r, nb);
     }
     const floatx4* __restrict__ X4 = reinterpret_cast<const floatx4*>(X) + lane;
     const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(Wp) + lane + (size_t)nb * Kb * 64;
@@ -65,7 +69,7 @@ __device__ __forceinline__ void conv_segment(const float* __restrict__ X, int Kb
             }
         });
 #pragma unroll
-    for (int r = 0; r < RTC; ++r) epi(rt0 + r, nb, acc[r] + acc2[r]);
+    for (int r = 0; r < RTC; ++r) epi(rt0 + r, nb, acc[r] + acc2[r], mul[r]);
 }
 
 template <int RT>
@@ -143,30 +147,48 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(bd_conv_args a) {
     const int U = nrt * Nb;
     const int ub = U / kWaves, urem = U - ub * kWaves;
     const int u0 = wave * ub + min(wave, urem), u1 = u0 + ub + (wave < urem ? 1 : 0);
-    auto epi = [&](int rt, int nb, floatx4 acc) {
+    auto outpos = [&](int nb, int& coff, int& need) {
         const int col = nb * 16 + (lane & 15);
-        if (col >= a.N) return;
-        int coff = col, need = 0;
+        coff = col;
+        need = 0;
         if (a.fuse_cq > 0) {            // column = class * Cq + channel: pixel (2y + py, 2x + px)
             const int cls = col / a.fuse_cq, py = cls >> 1, px = cls & 1;
             coff = (py * a.OW + px) * a.ldo + (col - cls * a.fuse_cq);
             need = py | (px << 1);
         }
+        return col < a.N;
+    };
+    auto pre = [&](int rt, int nb) {          // BD_ACT_ELU_GRAD: ELU'(saved output) of this lane's four elements
+        floatx4 m = floatx4{1.f, 1.f, 1.f, 1.f};
+        int coff, need;
+        if (a.act != BD_ACT_ELU_GRAD || !outpos(nb, coff, need)) return m;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = rt * 16 + 4 * (lane >> 4) + r;
             const int off = rowoff[row];
-            if (off >= 0 && (rowflag[row] & need) == need) a.out[(size_t)off + coff] = a.act ? elu(acc[r]) : acc[r];
+            if (off >= 0 && (rowflag[row] & need) == need) m[r] = elu_grad_from_out(a.aux[(size_t)off + coff]);
+        }
+        return m;
+    };
+    auto epi = [&](int rt, int nb, floatx4 acc, floatx4 mul) {
+        int coff, need;
+        if (!outpos(nb, coff, need)) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rt * 16 + 4 * (lane >> 4) + r;
+            const int off = rowoff[row];
+            if (off >= 0 && (rowflag[row] & need) == need)
+                a.out[(size_t)off + coff] = a.act == BD_ACT_ELU ? elu(acc[r]) : acc[r] * mul[r];
         }
     };
     int u = u0;
     while (u < u1) {
         const int nb = u / nrt, rt0 = u - nb * nrt;
         const int cnt = min(min(u1 - u, nrt - rt0), 4);
-        if (cnt == 4) conv_segment<4>(X, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi);
-        else if (cnt == 3) conv_segment<3>(X, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi);
-        else if (cnt == 2) conv_segment<2>(X, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi);
-        else conv_segment<1>(X, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi);
+        if (cnt == 4) conv_segment<4>(X, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi, pre);
+        else if (cnt == 3) conv_segment<3>(X, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi, pre);
+        else if (cnt == 2) conv_segment<2>(X, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi, pre);
+        else conv_segment<1>(X, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi, pre);
         u += cnt;
     }
 }
@@ -309,21 +331,22 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 // hit distinct bank groups), and the MFMA A fragment of (row tile, K block = (tap, 16 channels)) is one ds_read_b128 at
 //     rt_base[rt] + koff[kb] + (lane & 15) * sx * (C + 4) + 4 * (lane >> 4)
 // -- no im2col image at all.  Needs C % 16 == 0.  Same packed weights, same unit distribution, same epilogue.
-template <int RTC, class Epi>
+template <int RTC, class Epi, class Pre>
 __device__ __forceinline__ void patch_segment(const float* __restrict__ Pt, const int* __restrict__ koff,
                                               const int* __restrict__ rt_base, int rstride, int Kb,
                                               const float* __restrict__ Wp, const float* __restrict__ bias, int N, int bmod,
-                                              int nb, int rt0, Epi&& epi) {
+                                              int nb, int rt0, Epi&& epi, Pre&& pre) {
     const int lane = bd_tid() & 63;
     const int col = nb * 16 + (lane & 15);
     const float b = (bias != nullptr && col < N) ? bias[bmod > 0 ? col % bmod : col] : 0.f;
-    floatx4 acc[RTC], acc2[RTC];
+    floatx4 acc[RTC], acc2[RTC], mul[RTC];
     int abase[RTC];
 #pragma unroll
     for (int r = 0; r < RTC; ++r) {
         acc[r] = floatx4{b, b, b, b};
         acc2[r] = floatx4{0.f, 0.f, 0.f, 0.f};
         abase[r] = rt_base[rt0 + r] + (lane & 15) * rstride + 4 * (lane >> 4);
+        mul[r] = pre(rt0 + r, nb);
     }
     const floatx4* __restrict__ W4 = reinterpret_cast<const floatx4*>(Wp) + lane + (size_t)nb * Kb * 64;
     pipelined_k<2>(
@@ -349,7 +372,7 @@ __device__ __forceinline__ void patch_segment(const float* __restrict__ Pt, cons
             }
         });
 #pragma unroll
-    for (int r = 0; r < RTC; ++r) epi(rt0 + r, nb, acc[r] + acc2[r]);
+    for (int r = 0; r < RTC; ++r) epi(rt0 + r, nb, acc[r] + acc2[r], mul[r]);
 }
 
 template <int RT>
@@ -401,28 +424,46 @@ __global__ __launch_bounds__(kThreads) void conv_patch_kernel(bd_conv_args a, in
     const int ub = U / kWaves, urem = U - ub * kWaves;
     const int u0 = wave * ub + min(wave, urem), u1 = u0 + ub + (wave < urem ? 1 : 0);
     const int rstride = a.sx * Cp;
-    auto epi = [&](int rt, int nb, floatx4 acc) {
+    auto outpos = [&](int nb, int& coff, int& need) {
         const int col = nb * 16 + (lane & 15);
-        if (col >= a.N) return;
-        int coff = col, need = 0;
+        coff = col;
+        need = 0;
         if (a.fuse_cq > 0) {            // column = class * Cq + channel: pixel (2y + py, 2x + px)
             const int cls = col / a.fuse_cq, py = cls >> 1, px = cls & 1;
             coff = (py * a.OW + px) * a.ldo + (col - cls * a.fuse_cq);
             need = py | (px << 1);
         }
+        return col < a.N;
+    };
+    auto pre = [&](int rt, int nb) {          // BD_ACT_ELU_GRAD: ELU'(saved output) of this lane's four elements
+        floatx4 m = floatx4{1.f, 1.f, 1.f, 1.f};
+        int coff, need;
+        if (a.act != BD_ACT_ELU_GRAD || !outpos(nb, coff, need)) return m;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = rt * 16 + 4 * (lane >> 4) + r;
             const int off = rowoff[row];
-            if (off >= 0 && (rowflag[row] & need) == need) a.out[(size_t)off + coff] = a.act ? elu(acc[r]) : acc[r];
+            if (off >= 0 && (rowflag[row] & need) == need) m[r] = elu_grad_from_out(a.aux[(size_t)off + coff]);
+        }
+        return m;
+    };
+    auto epi = [&](int rt, int nb, floatx4 acc, floatx4 mul) {
+        int coff, need;
+        if (!outpos(nb, coff, need)) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rt * 16 + 4 * (lane >> 4) + r;
+            const int off = rowoff[row];
+            if (off >= 0 && (rowflag[row] & need) == need)
+                a.out[(size_t)off + coff] = a.act == BD_ACT_ELU ? elu(acc[r]) : acc[r] * mul[r];
         }
     };
     int u = u0;
     while (u < u1) {
         const int nb = u / nrt, rt0 = u - nb * nrt;
         const int cnt = min(min(u1 - u, nrt - rt0), 2);
-        if (cnt == 2) patch_segment<2>(Pt, koff, rt_base, rstride, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi);
-        else patch_segment<1>(Pt, koff, rt_base, rstride, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi);
+        if (cnt == 2) patch_segment<2>(Pt, koff, rt_base, rstride, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi, pre);
+        else patch_segment<1>(Pt, koff, rt_base, rstride, Kb, a.w, a.bias, a.N, a.fuse_cq, nb, rt0, epi, pre);
         u += cnt;
     }
 }
@@ -473,7 +514,8 @@ template <int KS>
 __global__ __launch_bounds__(kThreads) void conv_thin_f_kernel(const float* __restrict__ in, int imgs, int IH, int IW, int C,
                                                                int kk, const float* __restrict__ W, int ldw, int K,
                                                                const float* __restrict__ bias, int act,
-                                                               float* __restrict__ out, int gh, int gw, int ipw) {
+                                                               const float* __restrict__ aux, float* __restrict__ out, int gh, int gw,
+                                                               int ipw) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
@@ -522,6 +564,22 @@ __global__ __launch_bounds__(kThreads) void conv_thin_f_kernel(const float* __re
     for (; it < items; it += kWaves, b ^= 1) {
         // (the output stores of the previous item are still in flight: vmcnt counts them too, and retires in order, so the
         //  waits below also cover them -- a few hundred cycles per item that the other wave of the SIMD fills)
+        const int img = img0 + it / gh, y = it - (it / gh) * gh;
+        const size_t obase = ((size_t)img * gh + y) * gw * 32;
+        // BD_ACT_ELU_GRAD: the multipliers of this grid row, requested BEFORE the next band's DMA (vmcnt retires in order: a
+        // load issued after the DMA could only be waited for together with it)
+        float mul0[2][4], mul1[2][4];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mul0[rt][r] = mul1[rt][r] = 1.f;
+                const int x = rt * 16 + 4 * kq + r;
+                if (act == BD_ACT_ELU_GRAD && x < gw) {
+                    mul0[rt][r] = elu_grad_from_out(aux[obase + x * 32 + n]);
+                    mul1[rt][r] = elu_grad_from_out(aux[obase + x * 32 + 16 + n]);
+                }
+            }
         if (it + kWaves < items) {
             issue(it + kWaves, mine + (b ^ 1) * band_al);
             wait_keep_newest();
@@ -529,9 +587,10 @@ __global__ __launch_bounds__(kThreads) void conv_thin_f_kernel(const float* __re
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         const float* Bd = mine + b * band_al;
-        const int img = img0 + it / gh, y = it - (it / gh) * gh;
-        float* orow = out + ((size_t)img * gh + y) * gw * 32;
-        for (int rt = 0; rt < nrt; ++rt) {
+        float* orow = out + obase;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            if (rt >= nrt) break;
             const float* Bx = Bd + 2 * (rt * 16 + n) * C;              // A operand row m = lane & 15 -> pixel x = 16 rt + m
             floatx4 acc0 = floatx4{b0, b0, b0, b0}, acc1 = floatx4{b1, b1, b1, b1};
 #pragma unroll
@@ -544,8 +603,8 @@ __global__ __launch_bounds__(kThreads) void conv_thin_f_kernel(const float* __re
             for (int r = 0; r < 4; ++r) {
                 const int x = rt * 16 + 4 * kq + r;
                 if (x < gw) {
-                    orow[x * 32 + n] = act_apply(act, acc0[r]);
-                    orow[x * 32 + 16 + n] = act_apply(act, acc1[r]);
+                    orow[x * 32 + n] = act == BD_ACT_ELU ? elu(acc0[r]) : acc0[r] * mul0[rt][r];
+                    orow[x * 32 + 16 + n] = act == BD_ACT_ELU ? elu(acc1[r]) : acc1[r] * mul1[rt][r];
                 }
             }
         }
@@ -566,6 +625,7 @@ int bd_conv_gemm(const bd_conv_args* a, void* stream) {
     BD_REQUIRE((long)a->imgs * a->gh * a->gw < (1L << 31) && (long)a->imgs * a->OH * a->OW * a->ldo < (1L << 31),
                "bd_conv_gemm: image batch too large for 32-bit element offsets");
     BD_REQUIRE(!a->mask || (a->vec4 && (1 << a->cshift) == a->C), "bd_conv_gemm: masked gathers need C a power of two >= 4");
+    BD_REQUIRE(a->act != BD_ACT_ELU_GRAD || a->aux, "bd_conv_gemm: BD_ACT_ELU_GRAD needs the saved outputs (aux)");
     BD_REQUIRE(a->fuse_cq == 0 || (a->mask && a->N == 4 * a->fuse_cq && a->osy == 2 && a->osx == 2 && a->oy0 == 0 && a->ox0 == 0),
                "bd_conv_gemm: fused classes need pattern T with N = 4*fuse_cq");
     BD_REQUIRE(!a->vec4 || (a->C % 4 == 0 && a->seglen % 4 == 0), "bd_conv_gemm: vec4 gathers need C, seglen multiples of 4");
@@ -656,10 +716,11 @@ int bd_image_layout(const float* src, float* dst, int imgs, int C, int HW, int t
 }
 
 int bd_conv_thin_forward(const float* in, int imgs, int IH, int IW, int C, int k, const float* W, int ldw, const float* bias,
-                         int act, float* out, void* stream) {
+                         int act, const float* aux, float* out, void* stream) {
     using namespace bd;
     BD_REQUIRE(in && W && out && imgs > 0 && IH > 0 && IW > 0 && C >= 1 && C <= 4 && k >= 2 && IH >= k && IW >= k,
                "bd_conv_thin_forward: bad arguments");
+    BD_REQUIRE(act != BD_ACT_ELU_GRAD || aux, "bd_conv_thin_forward: BD_ACT_ELU_GRAD needs the saved outputs (aux)");
     const int K = k * k * C, gh = (IH - k) / 2 + 1, gw = (IW - k) / 2 + 1, roww = IW * C;
     BD_REQUIRE(K <= 4 * kThinSteps && ldw >= K && gw <= 32, "bd_conv_thin_forward: K = %d (<= %d), output width %d (<= 32)", K,
                4 * kThinSteps, gw);
@@ -671,12 +732,12 @@ int bd_conv_thin_forward(const float* in, int imgs, int IH, int IW, int C, int k
     hipStream_t s = (hipStream_t)stream;
     if (K <= 48) {
         if (lds > 64 * 1024 && allow_big_lds(conv_thin_f_kernel<12>)) return -1;
-        hipLaunchKernelGGL(conv_thin_f_kernel<12>, dim3(grid), dim3(kThreads), lds, s, in, imgs, IH, IW, C, k, W, ldw, K, bias, act, out,
-                           gh, gw, ipw);
+        hipLaunchKernelGGL(conv_thin_f_kernel<12>, dim3(grid), dim3(kThreads), lds, s, in, imgs, IH, IW, C, k, W, ldw, K, bias, act, aux,
+                           out, gh, gw, ipw);
     } else {
         if (lds > 64 * 1024 && allow_big_lds(conv_thin_f_kernel<kThinSteps>)) return -1;
         hipLaunchKernelGGL(conv_thin_f_kernel<kThinSteps>, dim3(grid), dim3(kThreads), lds, s, in, imgs, IH, IW, C, k, W, ldw, K, bias,
-                           act, out, gh, gw, ipw);
+                           act, aux, out, gh, gw, ipw);
     }
     BD_CHECK_LAUNCH("bd_conv_thin_forward");
     return 0;

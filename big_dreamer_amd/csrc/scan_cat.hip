@@ -417,7 +417,9 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
 #define a (*ap)
     const CatGeo g(a.D, a.C);
     const int Kb_h = cdiv(a.Be, 16), Kb_a = cdiv(a.A, 16), Kb_hd = cdiv(a.Hd, 16);
-    const int row0 = blockIdx.x * 16;
+    // a launch of fewer workgroups than tiles (host: whole rounds, see cat_grid) walks its tiles one after the other
+    for (int tile_ = blockIdx.x; tile_ * 16 < a.N; tile_ += gridDim.x) {
+    const int row0 = tile_ * 16;
     const int S = g.S, F = a.Be + S, A = a.A;
     const int nh = Kb_h * kFragFloats, nhd = Kb_hd * kFragFloats;
     const int rows_valid = a.N - row0 < 16 ? a.N - row0 : 16;
@@ -630,6 +632,8 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_fwd_kernel(bd_imagine_ca
         lds_barrier();
         float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
     }
+    lds_barrier();        // the next tile re-uses every LDS region
+    }
 #undef a
 }
 
@@ -642,7 +646,9 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_bwd_kernel(bd_imagine_ca
 #define a (*ap)
     const CatGeo g(a.D, a.C);
     const int Kb_h = cdiv(a.Be, 16), Kb_a = cdiv(a.A, 16), Kb_hd = cdiv(a.Hd, 16);
-    const int row0 = blockIdx.x * 16;
+    // a launch of fewer workgroups than tiles (host: whole rounds, see cat_grid) walks its tiles one after the other
+    for (int tile_ = blockIdx.x; tile_ * 16 < a.N; tile_ += gridDim.x) {
+    const int row0 = tile_ * 16;
     const int S = g.S, F = a.Be + S, A = a.A;
     const int nh = Kb_h * kFragFloats, nhd = Kb_hd * kFragFloats, na = Kb_a * kFragFloats;
     const int rows_valid = a.N - row0 < 16 ? a.N - row0 : 16;
@@ -852,7 +858,33 @@ __global__ __launch_bounds__(kThreads) void imagine_cat_bwd_kernel(bd_imagine_ca
         }
         }
     }
+    lds_barrier();        // the next tile re-uses every LDS region
+    }
 #undef a
+}
+
+// Launch geometry of the imagination scans.  A tile (16 rows) takes the same time whatever else runs, and tiles beyond the
+// chip's 256 CUs wait for a second round: 307 tiles (configs[4]: 4900 rows) are two rounds, the second one 20 % full, with
+// every CU held by a 120 KB workgroup for the whole launch.  The same two rounds on ceil(307 / 2) = 154 workgroups that walk
+// two tiles each take the behaviour-learning chain exactly as long and leave 102 CUs to the other streams (conv stacks,
+// weight gradients, critic) for the whole launch.  Such a launch asks for the CU's whole LDS so that its workgroups cannot
+// share a CU.  BD_CAT_TILE_LOOP=0: one workgroup per tile.  Returns the dynamic LDS size to request (0: error).
+template <class K>
+static size_t cat_grid(K kernel, int tiles, size_t lds, int* grid) {
+    static const char* e = getenv("BD_CAT_TILE_LOOP");
+    const int kCUs = 256;
+    *grid = tiles;
+    if (lds > 64 * 1024 && allow_big_lds(kernel)) return 0;
+    if (tiles <= kCUs || (e && e[0] == '0')) return lds;
+    const int rounds = cdiv(tiles, kCUs);
+    *grid = cdiv(tiles, rounds);
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(kernel)) != hipSuccess) {
+        fail("imagination scan: hipFuncGetAttributes failed");
+        return 0;
+    }
+    const size_t room = (size_t)kMaxLds > at.sharedSizeBytes ? (size_t)kMaxLds - at.sharedSizeBytes : 0;
+    return room > lds ? room : lds;
 }
 
 }  // namespace bd
@@ -927,8 +959,10 @@ int bd_imagine_cat_forward(const bd_imagine_cat_fwd_args* a, void* stream) {
     const size_t fixed = (size_t)(3 * Kb_h + 2 * Kb_hd + Kb_a) * kFragFloats + 16 * wmax + 3 * 16 * a->A + 2 * 16 * g.D;
     const size_t lds = (fixed + uni) * sizeof(float);      // every term of `fixed` is a multiple of 16 floats
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_imagine_cat_forward: needs %zu B of LDS", lds);
-    if (lds > 64 * 1024 && allow_big_lds(imagine_cat_fwd_kernel)) return -1;
-    hipLaunchKernelGGL(imagine_cat_fwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);
+    int grid;
+    const size_t dyn = cat_grid(imagine_cat_fwd_kernel, cdiv(a->N, 16), lds, &grid);
+    if (!dyn) return -1;
+    hipLaunchKernelGGL(imagine_cat_fwd_kernel, dim3(grid), dim3(kThreads), dyn, (hipStream_t)stream, *a);
     BD_CHECK_LAUNCH("bd_imagine_cat_forward");
     if (a->sv_act_stats != nullptr && a->eps_entropy != nullptr)     // the entropy estimate is off the recurrence (imagine.hip)
         return bd_actor_entropy(a->eps_entropy, a->sv_act_stats, a->entropy, a->Hm, a->N, a->A, a->n_samples, stream);
@@ -950,8 +984,10 @@ int bd_imagine_cat_backward(const bd_imagine_cat_bwd_args* a, void* stream) {
     if ((size_t)2 * Kb_hd * kFragFloats > uni) uni = (size_t)2 * Kb_hd * kFragFloats;
     const size_t lds = ((size_t)(6 * Kb_h + Kb_hd + 2 * Kb_a) * kFragFloats + uni) * sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_imagine_cat_backward: needs %zu B of LDS", lds);
-    if (lds > 64 * 1024 && allow_big_lds(imagine_cat_bwd_kernel)) return -1;
-    hipLaunchKernelGGL(imagine_cat_bwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);
+    int grid;
+    const size_t dyn = cat_grid(imagine_cat_bwd_kernel, cdiv(a->N, 16), lds, &grid);
+    if (!dyn) return -1;
+    hipLaunchKernelGGL(imagine_cat_bwd_kernel, dim3(grid), dim3(kThreads), dyn, (hipStream_t)stream, *a);
     BD_CHECK_LAUNCH("bd_imagine_cat_backward");
     return 0;
 }

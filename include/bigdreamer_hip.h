@@ -35,6 +35,8 @@ extern "C" {
 #define BD_MAX_LAYERS 6
 #define BD_ACT_NONE 0
 #define BD_ACT_ELU 1
+#define BD_ACT_ELU_GRAD 2   /* conv entry points only: out = value * ELU'(aux), aux = the SAVED ELU output at the same
+                            * index as out (the dgrad of a layer and the ELU backward of the layer below in one pass) */
 
 const char* bd_last_error(void);
 int bd_version(void);
@@ -112,6 +114,17 @@ size_t bd_wgrad_ws_floats(int M, int N, int K);
 int bd_wgrad(const float* dpre, int ldp, const float* act, int lda, int M, int N, int K,
              float* dW, int ldw, float* db, int accumulate, float* ws, size_t ws_floats, void* stream);
 
+/* The ONE-HOT columns of a first layer on [h; one-hot s] (Categorical latents; the heads of src/dreamer.py:320-322,370-391 on
+ * imagined features): dW[n][f*C + c] = sum over the rows m with sidx[m][f] == c of dpre[m][n], n < N -- what autograd computes
+ * as a dense K = D*C contraction with the 0/1 state, from the class indices the sampler wrote (csrc/wgrad_onehot.hip).  dW
+ * points at the first one-hot column of the [N][ldw] weight-gradient matrix and is OVERWRITTEN; rows [0, M1) take their
+ * indices from sidx1 [M1 x D], rows [M1, M) from sidx2[row - M1] (M1 = M, sidx2 = NULL: one source).  Fixed summation order.
+ * bd_wgrad_onehot_ok: the (D, C) this kernel takes (C <= 64); otherwise use the dense form (bd_wgrad on the dense state). */
+int bd_wgrad_onehot_ok(int D, int C);
+size_t bd_wgrad_onehot_ws_floats(int M, int N, int D, int C);
+int bd_wgrad_onehot(const float* dpre, int ldp, const unsigned char* sidx1, int M1, const unsigned char* sidx2, int M, int N, int D,
+                    int C, float* dW, int ldw, float* ws, size_t ws_floats, void* stream);
+
 /* Grouped form: every weight-gradient GEMM of one backward pass in ONE launch (+ one grouped reduce).  Fill the
  * caller fields of each descriptor on the host, let bd_wgrad_plan add the launch plan (and tell the slab workspace
  * size), copy the table to device memory once, then call bd_wgrad_grouped every step.  Rows [0, M1) take their
@@ -159,6 +172,7 @@ typedef struct {
     int fuse_cq;          /* pattern T with its four parity classes fused: N = 4*fuse_cq columns, column n = cls*fuse_cq
                            * + c goes to pixel (2y + (cls>>1), 2x + (cls&1)), channel c (osy = osx = 2, oy0 = ox0 = 0;
                            * gh x gw = the class-(0,0) grid; bias indexed by c); 0 = one class per call                */
+    const float* aux;     /* BD_ACT_ELU_GRAD: saved outputs, same layout as `out`; else unused                         */
 } bd_conv_args;
 int bd_conv_gemm(const bd_conv_args* a, void* stream);
 /* Stride-2 VALID convolution of a THIN image (C <= 4 channels) into 32 channels, NHWC: out (imgs, OH, OW, 32) =
@@ -166,7 +180,7 @@ int bd_conv_gemm(const bd_conv_args* a, void* stream);
  * as it lies in the buffer; bias may be NULL).  Conv2d(3 -> 32, k4) forward (src/models.py:538) and the dgrad of
  * ConvTranspose2d(32 -> 3, k6) (src/models.py:347).  k*k*C <= 108, OW <= 32. */
 int bd_conv_thin_forward(const float* in, int imgs, int IH, int IW, int C, int k, const float* W, int ldw, const float* bias,
-                         int act, float* out, void* stream);
+                         int act, const float* aux, float* out, void* stream);   /* aux: BD_ACT_ELU_GRAD only (else NULL) */
 /* dst (packed) [n = inner][k = (a, b', outer)] = src[outer][py+2a][px+2(Tb-1-b')][inner], src stored (outer, ky, kx, inner) */
 int bd_conv_pack_class(const float* src, float* dst, int Couter, int Cinner, int ksz, int py, int px, int Ta, int Tb,
                        void* stream);

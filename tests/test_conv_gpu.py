@@ -191,3 +191,59 @@ def test_thin_image_conv_forward_matches_cpu_fp32(imgs, k, bias, act):
     conv.thin_f(xs, out, ws, b.cuda() if bias else None, imgs, 64, 64, 3, k, cabi.ACT_ELU if act else cabi.ACT_NONE)
     torch.cuda.synchronize()
     _close(out.permute(0, 3, 1, 2), ref, 2e-5)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,size", ENC[1:])
+def test_dgrad_with_fused_elu_backward(Cin, Cout, k, size):
+    """BD_ACT_ELU_GRAD: the dgrad kernels multiply by ELU'(saved output of the layer below) in their epilogue -- the same
+    numbers as the plain dgrad followed by bd_elu_backward, on the T (fused classes) and the F pattern."""
+    from big_dreamer_amd import _cabi as cabi, conv
+    g = torch.Generator(device="cuda").manual_seed(11)
+    imgs = 5
+    w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) * 0.1
+    stored = w.permute(0, 2, 3, 1).contiguous()
+    OH = conv.conv_out(size, k)
+    gys = torch.randn(imgs, OH, OH, Cout, device="cuda", generator=g)
+    saved = Fnn.elu(torch.randn(imgs, size, size, Cin, device="cuda", generator=g))       # ELU outputs, both signs
+    fused = torch.zeros(conv.fused_pack_floats(Cout, Cin, k), device="cuda")
+    conv.pack_fused(stored, fused, Cout, Cin, k)
+    plain = torch.full((imgs, size, size, Cin), float("nan"), device="cuda")
+    conv.pattern_t_fused(gys, plain, fused, None, imgs, OH, OH, Cout, k, Cin, size, size, cabi.ACT_NONE)
+    cabi.check(cabi.lib.bd_elu_backward(cabi.ptr(plain), cabi.ptr(saved), plain.numel(), cabi.stream()))
+    got = torch.full((imgs, size, size, Cin), float("nan"), device="cuda")
+    conv.pattern_t_fused(gys, got, fused, None, imgs, OH, OH, Cout, k, Cin, size, size, cabi.ACT_ELU_GRAD, saved)
+    torch.cuda.synchronize()
+    assert torch.equal(got, plain)
+    # F pattern (dgrad of a transposed convolution): gradient image (imgs, HT, HT, Cin) -> (imgs, OH, OH, Cout)
+    HT = conv.convT_out(OH, k)
+    Kt = k * k * Cin
+    wp = torch.zeros(cabi.packed_floats(Cout, Kt), device="cuda")
+    conv.pack_matrix(stored.view(Cout, Kt), wp, Cout, Kt)
+    gyt = torch.randn(imgs, HT, HT, Cin, device="cuda", generator=g)
+    saved2 = Fnn.elu(torch.randn(imgs, OH, OH, Cout, device="cuda", generator=g))
+    plain2 = torch.full((imgs, OH, OH, Cout), float("nan"), device="cuda")
+    conv.pattern_f(gyt, plain2, wp, None, imgs, HT, HT, Cin, k, Cout, cabi.ACT_NONE)
+    cabi.check(cabi.lib.bd_elu_backward(cabi.ptr(plain2), cabi.ptr(saved2), plain2.numel(), cabi.stream()))
+    got2 = torch.full((imgs, OH, OH, Cout), float("nan"), device="cuda")
+    conv.pattern_f(gyt, got2, wp, None, imgs, HT, HT, Cin, k, Cout, cabi.ACT_ELU_GRAD, saved2)
+    torch.cuda.synchronize()
+    assert torch.equal(got2, plain2)
+
+
+@pytest.mark.parametrize("imgs", [3, 300])
+def test_thin_image_dgrad_with_fused_elu_backward(imgs):
+    """The same for bd_conv_thin_forward (dgrad of ConvTranspose2d(32 -> 3, k6): 64 x 64 x 3 gradient -> 30 x 30 x 32)."""
+    from big_dreamer_amd import _cabi as cabi, conv
+    g = torch.Generator(device="cuda").manual_seed(imgs)
+    k = 6
+    x = torch.randn(imgs, 64, 64, 3, device="cuda", generator=g)
+    ws = torch.randn(32, k * k * 3, device="cuda", generator=g) * 0.2
+    OH = conv.conv_out(64, k)
+    saved = Fnn.elu(torch.randn(imgs, OH, OH, 32, device="cuda", generator=g))
+    plain = torch.full((imgs, OH, OH, 32), float("nan"), device="cuda")
+    conv.thin_f(x, plain, ws, None, imgs, 64, 64, 3, k, cabi.ACT_NONE)
+    cabi.check(cabi.lib.bd_elu_backward(cabi.ptr(plain), cabi.ptr(saved), plain.numel(), cabi.stream()))
+    got = torch.full((imgs, OH, OH, 32), float("nan"), device="cuda")
+    conv.thin_f(x, got, ws, None, imgs, 64, 64, 3, k, cabi.ACT_ELU_GRAD, saved)
+    torch.cuda.synchronize()
+    assert torch.equal(got, plain)

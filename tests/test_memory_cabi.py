@@ -71,8 +71,8 @@ def test_config_overrides_like_hydra():
 
 def test_wgrad_plan_handles_conv_descriptors_on_the_host():
     """bd_wgrad_plan is host-only: a pass that mixes 2 450-row GEMMs with gathered conv weight gradients of up to
-    2.4 M rows gets per-GEMM row splits (all multiples of the 16-row stage, every GEMM covered), and inconsistent
-    gather geometry is rejected with a message."""
+    2.4 M rows gets per-GEMM row splits (multiples of the 16-row stage, or whole images for the 3-channel-image layers; every
+    GEMM covered), and inconsistent gather geometry is rejected with a message."""
     import ctypes as C
     from big_dreamer_amd import _cabi as cabi
     from big_dreamer_amd import conv
@@ -95,8 +95,14 @@ def test_wgrad_plan_handles_conv_descriptors_on_the_host():
     assert cabi.lib.bd_wgrad_plan(arr, len(descs), C.byref(tb), C.byref(tr), C.byref(wsf)) == 0, cabi.lib.bd_last_error()
     assert tb.value == sum(d.tiles_n * d.tiles_k * d.splits for d in arr) and tr.value > 0 and wsf.value > 0
     for d in arr:
-        assert d.rows_per % 16 == 0 and d.splits * d.rows_per >= d.M and (d.splits - 1) * d.rows_per < d.M
-        assert d.tiles_n * 13 * 16 >= d.N and d.tiles_k * 13 * 16 >= d.K
+        assert d.splits * d.rows_per >= d.M and (d.splits - 1) * d.rows_per < d.M
+        if d.g_pad == 1:        # a 3-channel-image layer on the wave-private bodies (wgrad.hip): whole images per workgroup
+            assert d.g_C == 3 and d.rows_per % (d.g_gh * d.g_gw) == 0 and d.tiles_n == 1 and d.tiles_k == 1
+        else:
+            assert d.rows_per % 16 == 0
+        # tiles are at most 13 blocks wide; narrow ones (<= 2 dpre blocks) may be 36 K blocks tall (wgrad.hip, deep tiles)
+        assert d.tiles_n * 13 * 16 >= d.N and d.tiles_k * 36 * 16 >= d.K
+    assert arr[3].g_pad == 1 and arr[4].g_pad == 0, "the thin-image body is for the C = 3 layers only"
     assert max(d.rows_per for d in arr) < 20000, "conv GEMMs must not leave millions of rows to one workgroup"
     bad = (cabi.WgradDesc * 1)(desc(imgs * 961, 32, 48, True, (4, 12, 31, 31, 60, 64, 3)))      # windows leave the image
     assert cabi.lib.bd_wgrad_plan(bad, 1, C.byref(tb), C.byref(tr), C.byref(wsf)) != 0
