@@ -59,11 +59,6 @@ def algorithmic(d):
                   "critic_fwd_bwd": (2 * head - 2 * F * d.Hd) * rows_img,   # forward + backward without d/d features
                   "wgrad_gemm_critic": head * rows_img,
                   "wgrad_gemm_actor": 2 * (actor) * rows_img})
-    if d.categorical and os.environ.get("BD_WGRAD_ONEHOT", "1") != "0":
-        # the one-hot columns of the two big first layers are segmented sums in their own kernel (csrc/wgrad_onehot.hip),
-        # outside the wgrad_gemm_* spans: the GEMM launch contracts the belief columns only
-        flops["wgrad_gemm_critic"] -= 2 * s_in * d.Hd * rows_img
-        flops["wgrad_gemm_actor"] -= 2 * s_in * d.Hd * rows_img
     # SURVEY.md section 8d algorithmic bytes: observe 4*(E+A+1+2S+Be+6S), imagine 4*(101A+2S+Be+3)+66, x3 fwd+bwd
     if d.categorical:   # per transition: read emb, action, mask, S draws; write belief, D indices (as floats), 2 x S logits
         obs_b = 4 * (d.E + d.A + 1 + d.S + d.Be + d.cat_D + 2 * d.S)

@@ -173,9 +173,6 @@ _SIGS = {
     "bd_mlp_set_tall": (I32, [I32]),
     "bd_wgrad_ws_floats": (C.c_size_t, [I32, I32, I32]),
     "bd_wgrad": (I32, [P, I32, P, I32, I32, I32, I32, P, I32, P, I32, P, C.c_size_t, P]),
-    "bd_wgrad_onehot_ok": (I32, [I32, I32]),
-    "bd_wgrad_onehot_ws_floats": (C.c_size_t, [I32, I32, I32, I32]),
-    "bd_wgrad_onehot": (I32, [P, I32, P, I32, P, I32, I32, I32, I32, P, I32, P, C.c_size_t, P]),
     "bd_wgrad_plan": (I32, [C.POINTER(WgradDesc), I32, C.POINTER(I32), C.POINTER(I32), C.POINTER(C.c_size_t)]),
     "bd_wgrad_grouped": (I32, [P, I32, I32, I32, P, P]),
     "bd_wgrad_grouped_phase": (I32, [P, I32, I32, I32, P, I32, P]),

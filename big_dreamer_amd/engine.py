@@ -197,21 +197,7 @@ class WgradBatch:
     def __init__(self, eng: "DreamerEngine", name: str, ws_attr: str = "_wgrad_ws"):
         self.eng, self.name, self.ws_attr = eng, name, ws_attr
         self.items: List[tuple] = []
-        self.onehot: List[tuple] = []
-        self._oh_ws: Optional[torch.Tensor] = None      # per batch: the actor's and the critic's passes run on different streams
         self._cache: Dict[tuple, tuple] = {}
-
-    def add_first_layer(self, dpre, ldp, feat, F, M, N, dW, db, sidx, feat2=None, M1=None, sidx2=None) -> None:
-        """Weight gradient of a first layer on features [h; s] (F = Be + S columns, rows [0, M1) from `feat`, the rest from
-        `feat2`).  Gaussian latents: one dense K = F GEMM.  Categorical latents with class indices at hand: the belief
-        columns as a dense K = Be GEMM, the one-hot columns as a segmented sum over the indices (bd_wgrad_onehot)."""
-        eng = self.eng
-        d = eng.d
-        if sidx is None or not eng.onehot_wgrad:
-            self.add(dpre, ldp, feat, F, M, N, F, dW, F, db, act2=feat2, lda2=F if feat2 is not None else 0, M1=M1)
-            return
-        self.add(dpre, ldp, feat, F, M, N, d.Be, dW, F, db, act2=feat2, lda2=F if feat2 is not None else 0, M1=M1)
-        self.onehot.append((dpre, ldp, sidx, M if M1 is None else M1, sidx2, M, N, dW))
 
     def add(self, dpre, ldp, act, lda, M, N, K, dW, ldw, db=None, act2=None, lda2=0, M1=None, gather=None) -> None:
         """gather = (nseg, seglen, gh, gw, IH, IW, C): `act` is an NHWC image and row m takes its stride-2 window
@@ -252,15 +238,6 @@ class WgradBatch:
         else:
             cabi.check(lib.bd_wgrad_grouped(table.data_ptr(), n, tb, tr, ws, cabi.stream()))
         self.items = []
-        d = eng.d
-        for (dpre, ldp, sidx, M1, sidx2, M, N, dW) in self.onehot:
-            need = int(lib.bd_wgrad_onehot_ws_floats(M, N, d.cat_D, d.cat_C))
-            if self._oh_ws is None or self._oh_ws.numel() < need:
-                self._oh_ws = torch.empty(need, dtype=torch.float32, device=eng.dev)
-            F = d.Be + d.S
-            cabi.check(lib.bd_wgrad_onehot(ptr(dpre), ldp, ptr(sidx), M1, ptr(sidx2), M, N, d.cat_D, d.cat_C,
-                                           dW.data_ptr() + 4 * d.Be, F, ptr(self._oh_ws), self._oh_ws.numel(), cabi.stream()))
-        self.onehot = []
 
 
 # Pipeline streams are per PROCESS and device, not per engine.  torch hands out streams from a fixed pool and HIP maps them
@@ -387,9 +364,6 @@ class DreamerEngine:
         self._buf: Dict[str, torch.Tensor] = {}
         # cluster variant of the observe scan (several CUs per 16-row tile): on unless BD_OBS_CLUSTER=0
         self.use_obs_cluster = os.environ.get("BD_OBS_CLUSTER", "1") != "0"
-        # Categorical latents: one-hot columns of the big first-layer weight gradients as segmented sums (csrc/wgrad_onehot.hip)
-        self.onehot_wgrad = (d.categorical and os.environ.get("BD_WGRAD_ONEHOT", "1") != "0"
-                             and bool(lib.bd_wgrad_onehot_ok(d.cat_D, d.cat_C)))
         self._obs_ws: Optional[torch.Tensor] = None
         self._obs_err_off: Optional[int] = None
         self._timers_on, self._timer_every, self._timer_tick = False, 1, 0
@@ -631,14 +605,9 @@ class DreamerEngine:
         cabi.check(lib.bd_wgrad(ptr(dpre), ldp, ptr(act), lda, M, N, K, ptr(dW), ldw, ptr(db), int(accumulate),
                                 ptr(self._wgrad_ws), self._wgrad_ws.numel(), cabi.stream()))
 
-    def _dense_wgrads(self, batch: "WgradBatch", mod: str, M: int, dpres, inp, ld_in, saves, sizes, sidx=None) -> None:
-        """Weight/bias gradients of a DenseModel from its pre-activation gradients (queued on `batch`).  `sidx`: class indices of
-        the one-hot state columns of `inp` = [h; s] (Categorical latents, big row counts): see WgradBatch.add_first_layer."""
+    def _dense_wgrads(self, batch: "WgradBatch", mod: str, M: int, dpres, inp, ld_in, saves, sizes) -> None:
+        """Weight/bias gradients of a DenseModel from its pre-activation gradients (queued on `batch`)."""
         for l in range(len(sizes) - 1):
-            if l == 0 and sidx is not None:
-                batch.add_first_layer(dpres[0], sizes[1], inp, ld_in, M, sizes[1], self.G(mod, "model.0.weight"),
-                                      self.G(mod, "model.0.bias"), sidx)
-                continue
             act, lda = (inp, ld_in) if l == 0 else (saves[l - 1], sizes[l])
             batch.add(dpres[l], sizes[l + 1], act, lda, M, sizes[l + 1], sizes[l],
                       self.G(mod, f"model.{2 * l}.weight"), sizes[l], self.G(mod, f"model.{2 * l}.bias"))
@@ -1628,8 +1597,7 @@ class DreamerEngine:
         Ga = lambda n: self.G("actor", n)
         wa = self._wbatch["actor"]
         # layer 0 input = [h_t; s_t]: start features for t = 0 (rows < N), imagined features of step t-1 afterwards
-        wa.add_first_layer(d_apre[0], d.Hd, feat, F, Mi, d.Hd, Ga("model.0.weight"), Ga("model.0.bias"),
-                           self._buf[ptag + "sidx"] if d.categorical else None, feat2=ifeat, M1=N, sidx2=isidx)
+        wa.add(d_apre[0], d.Hd, feat, F, Mi, d.Hd, F, Ga("model.0.weight"), F, Ga("model.0.bias"), act2=ifeat, lda2=F, M1=N)
         for l in range(1, DENSE_LAYERS):
             wa.add(d_apre[l], d.Hd, sv_actor[l - 1], d.Hd, Mi, d.Hd, d.Hd, Ga(f"model.{2 * l}.weight"), d.Hd,
                    Ga(f"model.{2 * l}.bias"))
@@ -1663,7 +1631,7 @@ class DreamerEngine:
             c_dpre = [self.buf(f"ic_dpre{l}", Mi, d.Hd) for l in range(DENSE_LAYERS)] + [d_c]
             self.mlp_backward(Mi, d_c, 1, c_layers, c_acts + [None], c_dpre[:-1] + [None])
         wc = self._wbatch["critic"]
-        self._dense_wgrads(wc, "critic", Mi, c_dpre, ifeat, F, c_acts, [F] + [d.Hd] * DENSE_LAYERS + [1], sidx=isidx)
+        self._dense_wgrads(wc, "critic", Mi, c_dpre, ifeat, F, c_acts, [F] + [d.Hd] * DENSE_LAYERS + [1])
         with self.span("wgrad_critic"):
             wc.run()
         self._optimizer_step_or_defer("opt_critic", "critic", SLOT_GN_CRITIC, hp["value_learning_rate"], red_ws)

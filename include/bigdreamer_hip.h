@@ -114,17 +114,6 @@ size_t bd_wgrad_ws_floats(int M, int N, int K);
 int bd_wgrad(const float* dpre, int ldp, const float* act, int lda, int M, int N, int K,
              float* dW, int ldw, float* db, int accumulate, float* ws, size_t ws_floats, void* stream);
 
-/* The ONE-HOT columns of a first layer on [h; one-hot s] (Categorical latents; the heads of src/dreamer.py:320-322,370-391 on
- * imagined features): dW[n][f*C + c] = sum over the rows m with sidx[m][f] == c of dpre[m][n], n < N -- what autograd computes
- * as a dense K = D*C contraction with the 0/1 state, from the class indices the sampler wrote (csrc/wgrad_onehot.hip).  dW
- * points at the first one-hot column of the [N][ldw] weight-gradient matrix and is OVERWRITTEN; rows [0, M1) take their
- * indices from sidx1 [M1 x D], rows [M1, M) from sidx2[row - M1] (M1 = M, sidx2 = NULL: one source).  Fixed summation order.
- * bd_wgrad_onehot_ok: the (D, C) this kernel takes (C <= 64); otherwise use the dense form (bd_wgrad on the dense state). */
-int bd_wgrad_onehot_ok(int D, int C);
-size_t bd_wgrad_onehot_ws_floats(int M, int N, int D, int C);
-int bd_wgrad_onehot(const float* dpre, int ldp, const unsigned char* sidx1, int M1, const unsigned char* sidx2, int M, int N, int D,
-                    int C, float* dW, int ldw, float* ws, size_t ws_floats, void* stream);
-
 /* Grouped form: every weight-gradient GEMM of one backward pass in ONE launch (+ one grouped reduce).  Fill the
  * caller fields of each descriptor on the host, let bd_wgrad_plan add the launch plan (and tell the slab workspace
  * size), copy the table to device memory once, then call bd_wgrad_grouped every step.  Rows [0, M1) take their

@@ -70,30 +70,3 @@ def test_categorical_kl_vs_reference_golden(name, tag, bal):
     _scaled("dpost", ql.grad.cpu().numpy(), want_q)
     _scaled("dprior", pl.grad.cpu().numpy(), want_p)
 
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("M,M1,N,D,C", [(37, 37, 20, 3, 5), (5000, 5000, 200, 32, 32), (3000, 1200, 200, 32, 32), (70, 10, 33, 9, 64)])
-def test_onehot_weight_gradient_matches_dense(M, M1, N, D, C):
-    """bd_wgrad_onehot (csrc/wgrad_onehot.hip): the one-hot columns of a first layer's weight gradient as segmented sums over
-    the class indices == dpre^T @ onehot(s) in fp64 on the CPU; rows from two index sources; columns beside the block untouched."""
-    from big_dreamer_amd import _cabi as cabi
-    assert cabi.lib.bd_wgrad_onehot_ok(D, C)
-    g = torch.Generator().manual_seed(M + N)
-    ldp, Be = N + 3, 8
-    dpre = torch.randn(M, ldp, generator=g)
-    sidx = torch.randint(0, C, (M, D), generator=g, dtype=torch.uint8)
-    onehot = torch.zeros(M, D * C, dtype=torch.float64)
-    onehot.view(M, D, C).scatter_(2, sidx.long().unsqueeze(-1), 1.0)
-    want = dpre[:, :N].double().t() @ onehot
-    ldw = Be + D * C + 5
-    dW = torch.full((N, ldw), 7.0, device="cuda")
-    s1, s2 = sidx[:M1].cuda().contiguous(), (sidx[M1:].cuda().contiguous() if M1 < M else None)
-    ws = torch.empty(int(cabi.lib.bd_wgrad_onehot_ws_floats(M, N, D, C)), device="cuda")
-    dp = dpre.cuda()
-    cabi.check(cabi.lib.bd_wgrad_onehot(cabi.ptr(dp), ldp, cabi.ptr(s1), M1, cabi.ptr(s2), M, N, D, C, dW.data_ptr() + 4 * Be, ldw,
-                                        cabi.ptr(ws), ws.numel(), cabi.stream()))
-    torch.cuda.synchronize()
-    got = dW.cpu()
-    assert torch.all(got[:, :Be] == 7.0) and torch.all(got[:, Be + D * C:] == 7.0), "columns outside the one-hot block were written"
-    err = float((got[:, Be:Be + D * C].double() - want).abs().max())
-    assert err <= 2e-5 * float(want.abs().max()) + 1e-6, err
