@@ -587,6 +587,15 @@ __global__ __launch_bounds__(kThreads) void imagine_bwd_kernel(bd_imagine_bwd_ar
 
 }  // namespace bd
 
+namespace bd {
+// BD_IMG_EXCLUSIVE=1 (experiment): a scan whose tiles fit the chip in one round asks for the CU's whole LDS, so that no
+// LDS-using workgroup of another stream shares a CU (and its issue slots) with a tile for the length of the launch.
+static size_t img_lds(size_t need, int tiles) {
+    static const char* e = getenv("BD_IMG_EXCLUSIVE");
+    return (e && e[0] == '1' && tiles <= 256) ? (size_t)kMaxLds : need;
+}
+}  // namespace bd
+
 extern "C" {
 using namespace bd;
 
@@ -618,8 +627,9 @@ static int imagine_forward_scan(const bd_imagine_fwd_args* a, void* stream) {
     const size_t lds = ((size_t)(3 * d.Kb_h + 2 * d.Kb_hd + d.Kb_s + d.Kb_a) * kFragFloats +
                         (size_t)(3 * 16 + kWaves * 16 * 3) * a->A + kSplitScratchFloats) * sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_imagine_forward: needs %zu B of LDS", lds);
-    if (lds > 64 * 1024 && allow_big_lds(imagine_fwd_kernel)) return -1;
-    hipLaunchKernelGGL(imagine_fwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);
+    const size_t dyn1 = img_lds(lds, cdiv(a->N, 16));
+    if (dyn1 > 64 * 1024 && allow_big_lds(imagine_fwd_kernel)) return -1;
+    hipLaunchKernelGGL(imagine_fwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), dyn1, (hipStream_t)stream, *a);
     BD_CHECK_LAUNCH("bd_imagine_forward");
     return 0;
 }
@@ -671,8 +681,9 @@ int bd_imagine_backward(const bd_imagine_bwd_args* a, void* stream) {
     const size_t lds = ((size_t)(6 * d.Kb_h + 3 * d.Kb_hd + 2 * d.Kb_s + 2 * d.Kb_a) * kFragFloats + 16 * a->S +
                         kSplitPartialFloats) * sizeof(float);
     BD_REQUIRE(lds <= (size_t)kMaxLds, "bd_imagine_backward: needs %zu B of LDS", lds);
-    if (lds > 64 * 1024 && allow_big_lds(imagine_bwd_kernel)) return -1;
-    hipLaunchKernelGGL(imagine_bwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), lds, (hipStream_t)stream, *a);
+    const size_t dyn2 = img_lds(lds, cdiv(a->N, 16));
+    if (dyn2 > 64 * 1024 && allow_big_lds(imagine_bwd_kernel)) return -1;
+    hipLaunchKernelGGL(imagine_bwd_kernel, dim3(cdiv(a->N, 16)), dim3(kThreads), dyn2, (hipStream_t)stream, *a);
     BD_CHECK_LAUNCH("bd_imagine_backward");
     return 0;
 }
