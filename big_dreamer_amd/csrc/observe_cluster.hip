@@ -580,11 +580,12 @@ size_t bd_observe_cluster_ws_floats(int B, int Be) {
 
 size_t bd_observe_cluster_err_offset(int B) { return cluster_ws_flag_floats(cdiv(B, 16)); }
 
-// which cluster form bd_observe_forward_cluster / _backward_cluster run wherever the K-split form applies: 2 = K-split with
-// granule hand-offs (observe_ksplit.hip, form R2), 1 = K-split with flag hand-offs (R1), 0 = the round-1 form (GRU columns
-// split, the rest redundant), -1 = default (environment BD_OBS_KSPLIT, else 1)
+// which cluster form bd_observe_forward_cluster / _backward_cluster run wherever the K-split form applies: 3 = K-split with the
+// forward GRU split by output columns (observe_ksplit.hip, two hand-offs per forward step), 1 = K-split in both directions
+// (three hand-offs), 2 = as 1 with granule hand-offs (R2), 0 = the round-1 form (GRU columns split, the rest redundant),
+// -1 = default (environment BD_OBS_KSPLIT, else 3)
 int bd_observe_cluster_set_ksplit(int mode) {
-    ksplit_mode() = mode < 0 ? -1 : (mode > 2 ? 2 : mode);
+    ksplit_mode() = mode < 0 ? -1 : (mode > 3 ? 3 : mode);
     return 0;
 }
 

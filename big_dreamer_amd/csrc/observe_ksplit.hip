@@ -181,6 +181,19 @@ __device__ __forceinline__ floatx4 mfma4(floatx4 a, floatx4 b, floatx4 acc) {
     for (int j = 0; j < 4; ++j) acc = mfma16(a[j], b[j], acc);
     return acc;
 }
+// Loop-invariant registers that were LOADED before the time loop (weight slices, biases, the initial carry): the compiler's
+// waitcnt pass cannot prove across the back edge that those loads have completed, so it puts `s_waitcnt vmcnt(0)` in front
+// of their first use in EVERY iteration -- which drains whatever the step has in flight at that point (the previous phase's
+// stores; operand prefetches issued at the top of the step: their whole HBM latency).  After one explicit wait the values
+// are passed through an empty asm: the loop then sees registers defined by the asm, not by a load.
+__device__ __forceinline__ void ks_settle(floatx4& v) { asm volatile("" : "+v"(v)); }
+template <int N>
+__device__ __forceinline__ void ks_settle(floatx4 (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) ks_settle(v[i]);
+}
+#define KS_SETTLE_BEGIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
 // packed weight fragment (out block nb, in block kb) of a matrix packed with Kb input blocks; zero when `ok` is false
 __device__ __forceinline__ floatx4 ks_frag(const float* w, int nb, int Kb, int kb, int lane, bool ok) {
     return ok ? reinterpret_cast<const floatx4*>(w)[((size_t)nb * Kb + kb) * 64 + lane] : floatx4{0.f, 0.f, 0.f, 0.f};
@@ -210,18 +223,25 @@ __device__ __forceinline__ floatx4 mfmaT(floatx4 w, floatx4 x, floatx4 acc) {
     for (int j = 0; j < 4; ++j) acc = mfma16(w[j], x[j], acc);
     return acc;
 }
-// four consecutive floats of a row-major row (16-byte load when the row start allows it)
+// four consecutive floats of a row-major row.  Rows of the feature tensors start at 4-byte granularity (F = Be + S floats), so
+// the 16-byte access goes through memcpy: the compiler emits ONE global_load / global_store_dwordx4 for a 4-byte aligned
+// address (gfx950 global memory takes unaligned vector accesses).  The earlier form branched on the address and fell back to
+// four predicated dword loads into a zero-initialised tuple -- a write-after-write on registers with loads in flight, which the
+// compiler guards with `s_waitcnt vmcnt(0)`: the operand prefetches of a step then completed one after the other.
 __device__ __forceinline__ floatx4 ks_row4(const float* p, int n_valid) {
     floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
-    if (n_valid >= 4 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) return *reinterpret_cast<const floatx4*>(p);
+    if (n_valid >= 4) {
+        __builtin_memcpy(&v, p, 16);
+        return v;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (i < n_valid) v[i] = p[i];
     return v;
 }
 __device__ __forceinline__ void ks_put4(float* p, floatx4 v, int n_valid) {
-    if (n_valid >= 4 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-        *reinterpret_cast<floatx4*>(p) = v;
+    if (n_valid >= 4) {
+        __builtin_memcpy(p, &v, 16);
         return;
     }
 #pragma unroll
@@ -275,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void observe_kfwd_kernel(bd_observe_fwd_a
     const int pair = wave % npairs, part = wave / npairs;
     const int pair_nb = pair >> 1, pair_raw = pair & 1;
     const bool has_pair = part == 0, sums_pair = part < nparts;
-    const floatx4 wh = ks_frag(pair_raw ? a.w_q2s : a.w_q2m, pair_nb, Kb_hd, c, lane, has_pair && c < Kb_hd);
+    floatx4 wh = ks_frag(pair_raw ? a.w_q2s : a.w_q2m, pair_nb, Kb_hd, c, lane, has_pair && c < Kb_hd);
     // this lane's elements: row frow, columns fcol0 .. fcol0 + 3 of block c
     const int frow = lane & 15, fcol0 = c * 16 + 4 * (lane >> 4);
     const int grow = row0 + frow;
@@ -311,6 +331,10 @@ __global__ __launch_bounds__(kThreads) void observe_kfwd_kernel(bd_observe_fwd_a
     }
     lds_barrier();
 
+    KS_SETTLE_BEGIN();
+    ks_settle(we_s); ks_settle(we_a); ks_settle(wg[0]); ks_settle(wg[1]); ks_settle(wq);
+    ks_settle(wh);
+    ks_settle(br4); ks_settle(bz4); ks_settle(bni4); ks_settle(bnh4); ks_settle(be4); ks_settle(bq4); ks_settle(bh4); ks_settle(h4);
     const bool lead = (c == 0);
     floatx4* __restrict__ RED4 = reinterpret_cast<floatx4*>(red);
     floatx4* __restrict__ REDB = RED4 + kWaves * 64;
@@ -341,20 +365,20 @@ __global__ __launch_bounds__(kThreads) void observe_kfwd_kernel(bd_observe_fwd_a
             n_ac = load_ac(t + 1, tid);
         }
         // ---- A: masked state / action fragments (every member; K of the embed layer is tiny) ----
-        for (int i = tid; i < 16 * Kb_s * 16; i += blockDim.x) {
+        // (ksplit_ok: 16 * S <= 512 threads, so these element loops are ONE pass and every thread uses the operands it
+        //  requested a step ahead -- a fallback load in the loop body would put a vmcnt wait on the common path)
+        if (tid < 16 * Kb_s * 16) {
+            const int i = tid;
             const int r = i / (Kb_s * 16), k = i - r * (Kb_s * 16);
             const int gr = row0 + r;
             float v = 0.f;
             if (gr < a.B && k < a.S) {
-                v = s_plain[r * a.S + k] * (i == tid ? c_nt : load_nt(t, i));
+                v = s_plain[r * a.S + k] * c_nt;
                 if (lead && a.sv_s) a.sv_s[(tb + gr) * a.S + k] = v;
             }
             sf[frag_idx(r, k)] = v;
         }
-        for (int i = tid; i < 16 * Kb_a * 16; i += blockDim.x) {
-            const int r = i / (Kb_a * 16), k = i - r * (Kb_a * 16);
-            af[frag_idx(r, k)] = i == tid ? c_ac : load_ac(t, i);
-        }
+        if (tid < 16 * Kb_a * 16) af[frag_idx(tid / (Kb_a * 16), tid % (Kb_a * 16))] = c_ac;
         // operands of the later epilogues: requested now, consumed after the hand-offs
         const floatx4 pre4 = rok ? ks_row4(a.pre_emb + (tb + grow) * a.Hd + fcol0, nhd) : z4;
         float eps = 0.f;
@@ -465,7 +489,8 @@ __global__ __launch_bounds__(kThreads) void observe_kfwd_kernel(bd_observe_fwd_a
             for (int i = 0; i < 4; ++i) pl[pair_raw * 16 * Np + frow * Np + pair_nb * 16 + 4 * (lane >> 4) + i] = v[i];
         }
         lds_barrier();
-        for (int e = tid; e < 16 * a.S; e += blockDim.x) {
+        if (tid < 16 * a.S) {
+            const int e = tid;
             const int row = e / a.S, col = e - row * a.S;
             const int gr = row0 + row;
             float st = 0.f;
@@ -475,7 +500,7 @@ __global__ __launch_bounds__(kThreads) void observe_kfwd_kernel(bd_observe_fwd_a
                     Mn += plain[pt * 2 * 16 * Np + row * Np + col];
                     Rw += plain[pt * 2 * 16 * Np + 16 * Np + row * Np + col];
                 }
-                const float ee = e == tid ? eps : a.eps_post[(tb + gr) * a.S + col];
+                const float ee = eps;
                 const float sd = softplusf(Rw) + a.min_std;
                 st = Mn + sd * ee;
                 if (lead) {
@@ -487,6 +512,327 @@ __global__ __launch_bounds__(kThreads) void observe_kfwd_kernel(bd_observe_fwd_a
             }
             s_plain[row * a.S + col] = st;
         }
+        lds_barrier();
+        BD_KSTAMP(11);
+    }
+#undef a
+}
+
+// ---- forward, GRU split by OUTPUT columns (two hand-offs per step) ---------------------------------------------------------
+// The K-split forward above pays three hand-offs per step, and the first one carries the gate partials of all 13 blocks
+// (52 KB per member).  Here member c forms the four gate pre-activations of ITS block over the full K instead:
+//   F1  x (ALL blocks) = ELU(W_e [s; a] + b)      every member, redundantly: K = S + A is tiny (wave w: blocks w, w + 8) -> LDS
+//   F2  R, Z, NI, NH of block c = W_i*[block c, :] x + W_h*[block c, :] h      K split over the WAVES (wave w: K blocks w, w + 8),
+//       partial sums meet in LDS -- no hand-off; the weights are the same 2 x 6 fragments per wave, other slices of them
+//   F3  h'_c = GRU gates of block c; stored into the exchange buffer as well: the belief all-gather
+//   F4  q partials over K block c -> reduce-scatter (hand-off 1; its flag also covers the belief block stored before it)
+//       ... then every member gathers the 13 belief blocks into LDS for the NEXT step's F2: off the critical path
+//   F5 - F7 as above (hand-off 2: head partials all-reduce)
+// The backward keeps its three hand-offs (its reduce-scatters carry gradients that no member can form alone).
+__global__ __launch_bounds__(kThreads) void observe_kfwd_ns_kernel(bd_observe_fwd_args a_, float* __restrict__ ws, int C, int tiles,
+                                                                   unsigned spin_limit) {
+    constexpr bool GR = false;
+    constexpr int IMG = KsImg<GR>::floats;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    BD_KARGS(bd_observe_fwd_args, ap);
+#define a (*ap)
+    const int Kb_h = cdiv(a.Be, 16), Kb_s = cdiv(a.S, 16), Kb_a = cdiv(a.A, 16), Kb_hd = cdiv(a.Hd, 16);
+    const int tile = blockIdx.x / C, c = blockIdx.x - tile * C;
+    const int row0 = tile * 16, F = a.Be + a.S, Np = Kb_s * 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* sf = smem;                               // masked state, fragment tiles
+    float* af = sf + Kb_s * kFragFloats;
+    float* s_plain = af + Kb_a * kFragFloats;       // [16][S]
+    float* red = s_plain + ((16 * a.S + 3) & ~3);   // [2][8 waves][64][4]: the two reductions of a step alternate
+    float* plain = red + 2 * kWaves * 256;          // [parts][2][16][Np]: head sums, one copy per helper wave group
+    float* xf = plain + kWaves * 256;               // x, all Kb_h blocks, fragment tiles
+    float* hf = xf + Kb_h * kFragFloats;            // h, all Kb_h blocks, fragment tiles
+    float* gpart = hf + Kb_h * kFragFloats;         // [8 waves][4 gates][64][4]: the waves' K-partial gate sums
+
+    unsigned* flags = reinterpret_cast<unsigned*>(ws) + tile * kMaxCluster;
+    unsigned* err = reinterpret_cast<unsigned*>(ws) + tiles * kMaxCluster;
+    const KsBuf kb_(C, GR);
+    float* xbase = ws + cluster_ws_header_floats(tiles) + (size_t)tile * kb_.copies * kb_.total;
+
+    // ---- resident weight slices ----
+    floatx4 we_s[2][kKsMaxS], we_a[2][kKsMaxA], be4x[2];      // embed: output blocks wave, wave + 8
+    floatx4 wg[2][6], wq[2];                                  // gates: block c, K blocks wave, wave + 8;  q: K block c
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int nbo = wave + kWaves * i;
+        const bool ok = nbo < Kb_h;
+#pragma unroll
+        for (int kb = 0; kb < kKsMaxS; ++kb) we_s[i][kb] = ks_frag(a.w_embed_s, nbo, Kb_s, kb, lane, ok && kb < Kb_s);
+#pragma unroll
+        for (int kb = 0; kb < kKsMaxA; ++kb) we_a[i][kb] = ks_frag(a.w_embed_a, nbo, Kb_a, kb, lane, ok && kb < Kb_a);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = nbo * 16 + 4 * (lane >> 4) + j;
+            be4x[i][j] = (ok && col < a.Be) ? a.b_embed[col] : 0.f;
+        }
+        wg[i][0] = ks_frag(a.w_ir, c, Kb_h, nbo, lane, ok); wg[i][1] = ks_frag(a.w_iz, c, Kb_h, nbo, lane, ok);
+        wg[i][2] = ks_frag(a.w_in, c, Kb_h, nbo, lane, ok); wg[i][3] = ks_frag(a.w_hr, c, Kb_h, nbo, lane, ok);
+        wg[i][4] = ks_frag(a.w_hz, c, Kb_h, nbo, lane, ok); wg[i][5] = ks_frag(a.w_hn, c, Kb_h, nbo, lane, ok);
+        wq[i] = ks_frag(a.w_q1h, nbo, Kb_h, c, lane, nbo < Kb_hd);
+    }
+    const int npairs = 2 * Kb_s, nparts = kWaves / npairs;
+    const int pair = wave % npairs, part = wave / npairs;
+    const int pair_nb = pair >> 1, pair_raw = pair & 1;
+    const bool has_pair = part == 0, sums_pair = part < nparts;
+    floatx4 wh = ks_frag(pair_raw ? a.w_q2s : a.w_q2m, pair_nb, Kb_hd, c, lane, has_pair && c < Kb_hd);
+    const int frow = lane & 15, fcol0 = c * 16 + 4 * (lane >> 4);
+    const int grow = row0 + frow;
+    const int nbe = a.Be - fcol0 < 0 ? 0 : (a.Be - fcol0 < 4 ? a.Be - fcol0 : 4);
+    const int nhd = a.Hd - fcol0 < 0 ? 0 : (a.Hd - fcol0 < 4 ? a.Hd - fcol0 : 4);
+    const bool rok = grow < a.B;
+    floatx4 br4 = floatx4{0.f, 0.f, 0.f, 0.f}, bz4 = br4, bni4 = br4, bnh4 = br4, bq4 = br4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < nbe) {
+            const int col = fcol0 + i;
+            br4[i] = a.b_ih[col] + a.b_hh[col];
+            bz4[i] = a.b_ih[a.Be + col] + a.b_hh[a.Be + col];
+            bni4[i] = a.b_ih[2 * a.Be + col];
+            bnh4[i] = a.b_hh[2 * a.Be + col];
+        }
+        if (i < nhd) bq4[i] = a.b_q1[fcol0 + i];
+    }
+    floatx4 bh4 = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (has_pair) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = pair_nb * 16 + 4 * (lane >> 4) + i;
+            if (col < a.S) bh4[i] = a.b_q2[pair_raw * a.S + col];
+        }
+    }
+    // ---- initial carries: this lane's elements of block c in registers, the whole belief as fragment tiles in LDS ----
+    floatx4 h4 = rok ? ks_row4(a.init_belief + (size_t)grow * a.Be + fcol0, nbe) : floatx4{0.f, 0.f, 0.f, 0.f};
+    floatx4* __restrict__ XF4 = reinterpret_cast<floatx4*>(xf);
+    floatx4* __restrict__ HF4 = reinterpret_cast<floatx4*>(hf);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int nbo = wave + kWaves * i;
+        if (nbo < Kb_h) {
+            const int col0 = nbo * 16 + 4 * (lane >> 4);
+            const int nv = a.Be - col0 < 0 ? 0 : (a.Be - col0 < 4 ? a.Be - col0 : 4);
+            HF4[nbo * 64 + lane] = rok ? ks_row4(a.init_belief + (size_t)grow * a.Be + col0, nv) : floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // the first step's masked state / action fragments (later steps: written by the sampling phase of the step before)
+    for (int i = threadIdx.x; i < 16 * Kb_s * 16; i += blockDim.x) {
+        const int r = i / (Kb_s * 16), k = i - r * (Kb_s * 16);
+        float v = 0.f;
+        if (row0 + r < a.B && k < a.S) {
+            v = a.init_state[(size_t)(row0 + r) * a.S + k] * (a.nonterm ? a.nonterm[row0 + r] : 1.f);
+            if (c == 0 && a.sv_s) a.sv_s[(size_t)(row0 + r) * a.S + k] = v;
+        }
+        sf[frag_idx(r, k)] = v;
+    }
+    for (int i = threadIdx.x; i < 16 * Kb_a * 16; i += blockDim.x) {
+        const int r = i / (Kb_a * 16), k = i - r * (Kb_a * 16);
+        af[frag_idx(r, k)] = (row0 + r < a.B && k < a.A) ? a.actions[(size_t)(row0 + r) * a.A + k] : 0.f;
+    }
+    lds_barrier();
+
+    KS_SETTLE_BEGIN();
+    ks_settle(we_s[0]); ks_settle(we_s[1]); ks_settle(we_a[0]); ks_settle(we_a[1]); ks_settle(be4x);
+    ks_settle(wg[0]); ks_settle(wg[1]); ks_settle(wq);
+    ks_settle(wh);
+    ks_settle(br4); ks_settle(bz4); ks_settle(bni4); ks_settle(bnh4); ks_settle(bq4); ks_settle(bh4); ks_settle(h4);
+    const bool lead = (c == 0);
+    floatx4* __restrict__ RED4 = reinterpret_cast<floatx4*>(red);
+    floatx4* __restrict__ REDB = RED4 + kWaves * 64;
+    floatx4* __restrict__ GP4 = reinterpret_cast<floatx4*>(gpart);
+    const floatx4 z4 = floatx4{0.f, 0.f, 0.f, 0.f};
+    bool dead = false;
+
+    // operands of the NEXT step's fragments, in the sampling phase's element order (e -> row e / S), requested a step ahead
+    auto load_nt = [&](int t, int e) {
+        const int r = e / a.S;
+        return (a.nonterm && t < a.T && e < 16 * a.S && row0 + r < a.B) ? a.nonterm[(size_t)t * a.B + row0 + r] : 1.f;
+    };
+    auto load_ac = [&](int t, int i) {
+        const int r = i / (Kb_a * 16), k = i - r * (Kb_a * 16);
+        return (t < a.T && i < 16 * Kb_a * 16 && row0 + r < a.B && k < a.A) ? a.actions[((size_t)t * a.B + row0 + r) * a.A + k] : 0.f;
+    };
+
+    for (int t = 0; t < a.T; ++t) {
+        const size_t tb = (size_t)t * a.B;
+        const int tid = bd_tid();
+        float* xb = xbase + (size_t)(t & 1) * kb_.total;
+        float* hx = xb + kb_.g;                      // [src][256]: the belief blocks (the gate-partial region is free in this form)
+        BD_KSTAMP(0);
+        BD_KARGS_FRESH(ap);
+        // (no phase A: this step's masked state / action fragments were written by the step before)
+        BD_KSTAMP(1);
+        // ---- F1: x, blocks wave and wave + 8 -> fragment tiles in LDS ----
+        // Branch-free: both blocks' MFMA chains in ONE basic block so that they interleave (absent blocks and absent K blocks
+        // carry zero weights; their operand reads are clamped to a valid fragment so that 0 x value stays finite).
+        {
+            const floatx4* __restrict__ S4 = reinterpret_cast<const floatx4*>(sf) + lane;
+            const floatx4* __restrict__ A4 = reinterpret_cast<const floatx4*>(af) + lane;
+            floatx4 sk[kKsMaxS], ak[kKsMaxA];
+#pragma unroll
+            for (int kb = 0; kb < kKsMaxS; ++kb) sk[kb] = S4[(kb < Kb_s ? kb : Kb_s - 1) * 64];
+#pragma unroll
+            for (int kb = 0; kb < kKsMaxA; ++kb) ak[kb] = A4[(kb < Kb_a ? kb : Kb_a - 1) * 64];
+            floatx4 acc0 = be4x[0], acc1 = be4x[1];
+#pragma unroll
+            for (int kb = 0; kb < kKsMaxS; ++kb) {
+                acc0 = mfmaT(we_s[0][kb], sk[kb], acc0);
+                acc1 = mfmaT(we_s[1][kb], sk[kb], acc1);
+            }
+#pragma unroll
+            for (int kb = 0; kb < kKsMaxA; ++kb) {
+                acc0 = mfmaT(we_a[0][kb], ak[kb], acc0);
+                acc1 = mfmaT(we_a[1][kb], ak[kb], acc1);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int nbo = wave + kWaves * i;
+                const floatx4 acc = i ? acc1 : acc0;
+                floatx4 x4;
+                const int col0 = nbo * 16 + 4 * (lane >> 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x4[j] = (rok && col0 + j < a.Be) ? elu(acc[j]) : 0.f;
+                if (nbo < Kb_h) {
+                    XF4[nbo * 64 + lane] = x4;
+                    if (nbo == c && rok && a.sv_x) ks_put4(a.sv_x + (tb + grow) * a.Be + fcol0, x4, nbe);
+                }
+            }
+        }
+        lds_barrier();
+        BD_KSTAMP(2);
+        BD_KARGS_FRESH(ap);
+        // ---- F2: gate pre-activations of block c: this wave's K blocks; the eight partial sums meet in LDS ----
+        {
+            floatx4 R = z4, Z = z4, NI = z4, NH = z4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int kb = wave + kWaves * i;
+                if (kb < Kb_h) {
+                    const floatx4 xk = XF4[kb * 64 + lane], hk = HF4[kb * 64 + lane];
+                    R = mfmaT(wg[i][0], xk, R); Z = mfmaT(wg[i][1], xk, Z); NI = mfmaT(wg[i][2], xk, NI);
+                    R = mfmaT(wg[i][3], hk, R); Z = mfmaT(wg[i][4], hk, Z); NH = mfmaT(wg[i][5], hk, NH);
+                }
+            }
+            GP4[(wave * 4 + 0) * 64 + lane] = R; GP4[(wave * 4 + 1) * 64 + lane] = Z;
+            GP4[(wave * 4 + 2) * 64 + lane] = NI; GP4[(wave * 4 + 3) * 64 + lane] = NH;
+        }
+        lds_barrier();
+        BD_KSTAMP(3);
+        BD_KSTAMP(4);
+        // ---- F3: wave = (gate, half of the waves' partials), then every wave finishes the GRU gates ----
+        {
+            const int g = wave & 3, half = wave >> 2;
+            floatx4 s4 = z4;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s4 += GP4[((half * 4 + w) * 4 + g) * 64 + lane];
+            RED4[wave * 64 + lane] = s4;
+        }
+        lds_barrier();
+        {
+            const floatx4 R = RED4[0 * 64 + lane] + RED4[4 * 64 + lane] + br4, Z = RED4[1 * 64 + lane] + RED4[5 * 64 + lane] + bz4;
+            const floatx4 NI = RED4[2 * 64 + lane] + RED4[6 * 64 + lane] + bni4, NH = RED4[3 * 64 + lane] + RED4[7 * 64 + lane] + bnh4;
+            floatx4 rr4, zz4, nn4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rr4[i] = sigmoidf(R[i]);
+                zz4[i] = sigmoidf(Z[i]);
+                nn4[i] = tanh_act(NI[i] + rr4[i] * NH[i]);
+                h4[i] = (rok && i < nbe) ? (1.f - zz4[i]) * nn4[i] + zz4[i] * h4[i] : 0.f;
+            }
+            if (wave == 0) {
+                ks_store4(hx + (size_t)c * 256 + lane * 4, h4);        // the belief all-gather: announced by the next publish
+                if (rok) {
+                    ks_put4(a.feat + (tb + grow) * F + fcol0, h4, nbe);
+                    if (a.sv_gates) {
+                        float* gg = a.sv_gates + (tb + grow) * 4 * a.Be + fcol0;
+                        ks_put4(gg, rr4, nbe); ks_put4(gg + a.Be, zz4, nbe); ks_put4(gg + 2 * a.Be, nn4, nbe); ks_put4(gg + 3 * a.Be, NH, nbe);
+                    }
+                }
+            }
+        }
+        BD_KSTAMP(5);
+        BD_KARGS_FRESH(ap);
+        // operands of the later phases and of the next step: requested HERE, behind the phases that issue no loads (a load in
+        // flight at the top of the step made the compiler drain vmcnt in front of F1's MFMAs: 3k cycles per step)
+        const float n_nt = load_nt(t + 1, tid), n_ac = load_ac(t + 1, tid);
+        const floatx4 pre4 = rok ? ks_row4(a.pre_emb + (tb + grow) * a.Hd + fcol0, nhd) : z4;
+        float eps = 0.f;
+        {
+            const int row = tid / a.S, col = tid - row * a.S;
+            if (tid < 16 * a.S && row0 + row < a.B) eps = a.eps_post[(tb + row0 + row) * a.S + col];
+        }
+        // ---- F4: posterior-hidden partials over K block c; reduce-scatter (hand-off 1) ----
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int nbo = wave + kWaves * i;
+            if (nbo < Kb_hd) ks_emit<GR>(xb + kb_.q + (size_t)(nbo * C + c) * IMG, lane, mfmaT(wq[i], h4, z4), (unsigned)(3 * t + 2));
+        }
+        BD_KSTAMP(6);
+        ks_handoff<GR>(flags, c, C, (unsigned)(3 * t + 2), err, spin_limit, kErrFwd);
+        BD_KSTAMP(7);
+        // ---- F5: q_c = ELU(sum + pre_emb_c + b); and the belief blocks of all members into LDS for the next step's F2 ----
+        REDB[wave * 64 + lane] = c < Kb_hd ? ks_reduce<GR>(xb + kb_.q + (size_t)(c * C) * IMG, IMG, wave, kWaves, C, lane,
+                                                          (unsigned)(3 * t + 2), err, spin_limit, kErrFwd, dead) : z4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int nbo = wave + kWaves * i;
+            if (nbo < Kb_h) HF4[nbo * 64 + lane] = ks_load4(hx + (size_t)nbo * 256 + lane * 4);     // (read again only after barriers)
+        }
+        lds_barrier();
+        floatx4 q4 = bq4 + pre4;
+        for (int w = 0; w < kWaves; ++w) q4 += REDB[w * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q4[i] = (rok && i < nhd) ? elu(q4[i]) : 0.f;
+        if (wave == 0 && rok && a.sv_q) ks_put4(a.sv_q + (tb + grow) * a.Hd + fcol0, q4, nhd);
+        BD_KSTAMP(8);
+        BD_KARGS_FRESH(ap);
+        // ---- F6: (mean, raw) partials over K block c; all-reduce (hand-off 2) ----
+        if (has_pair) ks_emit<GR>(xb + kb_.s + (size_t)(c * 8 + pair) * IMG, lane, mfmaT(wh, q4, z4), (unsigned)(3 * t + 3));
+        BD_KSTAMP(9);
+        ks_handoff<GR>(flags, c, C, (unsigned)(3 * t + 3), err, spin_limit, kErrFwd);
+        BD_KSTAMP(10);
+        BD_KARGS_FRESH(ap);
+        // ---- F7: every member sums the head partials, then samples s' ----
+        if (sums_pair) {
+            floatx4 v = ks_reduce<GR>(xb + kb_.s + (size_t)pair * IMG, (size_t)8 * IMG, part, nparts, C, lane, (unsigned)(3 * t + 3), err,
+                                      spin_limit, kErrFwd, dead);
+            if (part == 0) v += bh4;
+            float* pl = plain + (size_t)part * 2 * 16 * Np;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pl[pair_raw * 16 * Np + frow * Np + pair_nb * 16 + 4 * (lane >> 4) + i] = v[i];
+        }
+        lds_barrier();
+        if (tid < 16 * a.S) {
+            const int e = tid;
+            const int row = e / a.S, col = e - row * a.S;
+            const int gr = row0 + row;
+            float st = 0.f;
+            if (gr < a.B) {
+                float Mn = plain[row * Np + col], Rw = plain[16 * Np + row * Np + col];
+                for (int pt = 1; pt < nparts; ++pt) {
+                    Mn += plain[pt * 2 * 16 * Np + row * Np + col];
+                    Rw += plain[pt * 2 * 16 * Np + 16 * Np + row * Np + col];
+                }
+                const float ee = eps;
+                const float sd = softplusf(Rw) + a.min_std;
+                st = Mn + sd * ee;
+                if (lead) {
+                    const size_t ix = (tb + gr) * a.S + col;
+                    a.post_mean[ix] = Mn;
+                    a.post_std[ix] = sd;
+                    a.feat[(tb + gr) * F + a.Be + col] = st;
+                }
+            }
+            // the next step's input: s' through that step's nonterminal mask, straight into the fragment tile
+            const float mv = st * n_nt;
+            sf[frag_idx(row, col)] = mv;
+            if (lead && a.sv_s && t + 1 < a.T && gr < a.B) a.sv_s[(tb + a.B + gr) * a.S + col] = mv;
+        }
+        if (tid < 16 * Kb_a * 16) af[frag_idx(tid / (Kb_a * 16), tid % (Kb_a * 16))] = n_ac;
         lds_barrier();
         BD_KSTAMP(11);
     }
@@ -536,7 +882,7 @@ __global__ __launch_bounds__(kThreads) void observe_kbwd_kernel(bd_observe_bwd_a
         wg[i][4] = ks_frag(a.wt_hz, nbo, Kb_h, c, lane, ok); wg[i][5] = ks_frag(a.wt_hn, nbo, Kb_h, c, lane, ok);
     }
     const int sblk = wave % Kb_s, spart = wave / Kb_s;
-    const floatx4 wes = ks_frag(a.wt_embed_s, sblk, Kb_h, c, lane, spart == 0);  // (out = S, in = Be): state block of this wave
+    floatx4 wes = ks_frag(a.wt_embed_s, sblk, Kb_h, c, lane, spart == 0);  // (out = S, in = Be): state block of this wave
     const int frow = lane & 15, fcol0 = c * 16 + 4 * (lane >> 4);
     const int grow = row0 + frow;
     const int nbe = a.Be - fcol0 < 0 ? 0 : (a.Be - fcol0 < 4 ? a.Be - fcol0 : 4);
@@ -546,6 +892,9 @@ __global__ __launch_bounds__(kThreads) void observe_kbwd_kernel(bd_observe_bwd_a
     for (int i = threadIdx.x; i < nparts * dsp_stride; i += blockDim.x) ds_plain[i] = 0.f;
     lds_barrier();
 
+    KS_SETTLE_BEGIN();
+    ks_settle(w2m); ks_settle(w2s); ks_settle(w1); ks_settle(wg[0]); ks_settle(wg[1]);
+    ks_settle(wes);
     const bool lead = (c == 0);
     floatx4* __restrict__ RED4 = reinterpret_cast<floatx4*>(red);
     floatx4* __restrict__ REDB = RED4 + kWaves * 64;
@@ -616,12 +965,13 @@ __global__ __launch_bounds__(kThreads) void observe_kbwd_kernel(bd_observe_bwd_a
             sv = load_sv(t);
         }
         // ---- B1: through the sample / softplus into (mean, raw) (every member, elementwise) ----
-        for (int i = tid; i < 16 * Kb_s * 16; i += blockDim.x) {
+        if (tid < 16 * Kb_s * 16) {          // (one pass: see the forward kernels)
+            const int i = tid;
             const int r = i / (Kb_s * 16), k = i - r * (Kb_s * 16);
             const int gr = row0 + r;
             float dm = 0.f, dr = 0.f;
             if (gr < a.B && k < a.S) {
-                const B1v v = i == tid ? cb1 : load_b1(t, i);
+                const B1v v = cb1;
                 float dst = v.dfs;
                 for (int pt = 0; pt < nparts; ++pt) dst += ds_plain[pt * dsp_stride + r * a.S + k];
                 dm = dst + v.dpm;
@@ -763,14 +1113,14 @@ size_t ksplit_ws_floats_per_tile(int C) {
 }
 
 int& ksplit_mode() {               // -1: as the environment says, 0: off (round-1 cluster form), 1: K-split with R1 hand-offs,
-    static int m = -1;             //  2: K-split with granule (R2) hand-offs
+    static int m = -1;             //  2: K-split with granule (R2) hand-offs, 3: as 1 with the forward GRU split by output columns
     return m;
 }
-static int ksplit_form() {         // 0 / 1 / 2 as above, environment resolved (BD_OBS_KSPLIT, default 1)
+static int ksplit_form() {         // 0 / 1 / 2 / 3 as above, environment resolved (BD_OBS_KSPLIT, default 3)
     static const char* e = getenv("BD_OBS_KSPLIT");
     if (ksplit_mode() >= 0) return ksplit_mode();
-    if (e && e[0] >= '0' && e[0] <= '2') return e[0] - '0';
-    return 1;
+    if (e && e[0] >= '0' && e[0] <= '3') return e[0] - '0';
+    return 3;
 }
 
 bool ksplit_ok(int Be, int S, int A, int Hd, int C) {
@@ -783,6 +1133,9 @@ static size_t ks_lds_fwd(int S, int A) {
     const int Kb_s = cdiv(S, 16), Kb_a = cdiv(A, 16);
     const int nparts = kWaves / (2 * Kb_s);
     return ((size_t)(Kb_s + Kb_a) * kFragFloats + ((16 * S + 3) & ~3) + 2 * kWaves * 256 + (size_t)nparts * 2 * 16 * Kb_s * 16) * sizeof(float);
+}
+static size_t ks_lds_fwd_ns(int S, int A, int Be) {       // + x and h fragment tiles + the waves' gate partials
+    return ks_lds_fwd(S, A) + ((size_t)2 * cdiv(Be, 16) * kFragFloats + (size_t)kWaves * 4 * 256) * sizeof(float);
 }
 static size_t ks_lds_bwd(int S) {
     const int Kb_s = cdiv(S, 16);
@@ -824,7 +1177,18 @@ static int launch_kbwd(const bd_observe_bwd_args* a, float* ws, int C, int tiles
     return 0;
 }
 
+static int launch_kfwd_ns(const bd_observe_fwd_args* a, float* ws, int C, int tiles, hipStream_t stream) {
+    if (allow_big_lds(observe_kfwd_ns_kernel)) return -1;
+    const size_t dyn = launch_lds(observe_kfwd_ns_kernel, ks_lds_fwd_ns(a->S, a->A, a->Be), "bd_observe_forward_cluster");
+    if (!dyn) return -1;
+    if (ks_reset(ws, C, tiles, false, stream, "bd_observe_forward_cluster")) return -1;
+    hipLaunchKernelGGL(observe_kfwd_ns_kernel, dim3(tiles * C), dim3(kThreads), dyn, stream, *a, ws, C, tiles, cluster_spin_limit());
+    BD_CHECK_LAUNCH("bd_observe_forward_cluster");
+    return 0;
+}
+
 int launch_observe_kfwd(const bd_observe_fwd_args* a, float* ws, int C, int tiles, hipStream_t stream) {
+    if (ksplit_form() == 3) return launch_kfwd_ns(a, ws, C, tiles, stream);
     return ksplit_form() == 2 ? launch_kfwd<true>(a, ws, C, tiles, stream) : launch_kfwd<false>(a, ws, C, tiles, stream);
 }
 int launch_observe_kbwd(const bd_observe_bwd_args* a, float* ws, int C, int tiles, hipStream_t stream) {

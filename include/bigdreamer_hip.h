@@ -267,8 +267,10 @@ int bd_observe_cluster_size(int B, int Be);   /* workgroups per 16-row tile; 0 =
  * partials all-reduce: three hand-offs per step, nothing computed redundantly.  Round 1 (csrc/observe_cluster.hip, wide
  * batches with two belief blocks per member, or bd_observe_cluster_set_ksplit(0)): only the GRU is split, by output
  * columns, one all-gather per step, the small layers recomputed by every member.  Identical arguments and results. */
-int bd_observe_cluster_set_ksplit(int mode);  /* 2 = K-split, granule hand-offs ("the data is the flag"); 1 = K-split, flag
-                                               * hand-offs; 0 = round-1 form; -1 = default (environment BD_OBS_KSPLIT, else 1) */
+int bd_observe_cluster_set_ksplit(int mode);  /* 3 = K-split, forward GRU split by output columns (two hand-offs per forward
+                                               * step; the default); 1 = K-split, GRU split along K in both directions;
+                                               * 2 = as 1 with granule hand-offs ("the data is the flag"); 0 = round-1 form;
+                                               * -1 = default (environment BD_OBS_KSPLIT, else 3) */
 size_t bd_observe_cluster_ws_floats(int B, int Be);
 int bd_observe_forward_cluster(const bd_observe_fwd_args* a, float* ws, size_t ws_floats, void* stream);
 int bd_observe_backward_cluster(const bd_observe_bwd_args* a, float* ws, size_t ws_floats, void* stream);

@@ -101,6 +101,9 @@ def test_forward_pieces_vs_oracle(name):
                                           # the K-split form with granule ("the data is the flag") hand-offs
                                           ("small", "ksplit_gr"), ("tiny_freenats0", "ksplit_gr"), ("config1", "ksplit_gr"),
                                           ("config2", "ksplit_gr"),
+                                          # the K-split form whose forward also splits the GRU along K (three hand-offs per step)
+                                          ("small", "ksplit_r1"), ("tiny_freenats0", "ksplit_r1"), ("config1", "ksplit_r1"),
+                                          ("config2", "ksplit_r1"),
                                           ("tiny_pixel", True), ("tiny_pixel_lin", True),
                                           ("tiny_pixel", "miopen"), ("tiny_pixel_lin", "miopen"),
                                           ("config3", True), ("tiny_discount", True), ("tiny_discount", False)])
@@ -112,10 +115,11 @@ def test_train_steps_vs_oracle_and_golden(name, cluster, monkeypatch):
     torch_convs = cluster == "miopen"
     if torch_convs:
         cluster = True
-    # cluster=True: the K-split cluster scan (csrc/observe_ksplit.hip, the default: flag hand-offs); "ksplit_gr": the same scan
-    # with granule hand-offs; "round1": observe_cluster.hip's form; False: one workgroup per tile (observe.hip)
-    cabi.check(cabi.lib.bd_observe_cluster_set_ksplit({"round1": 0, "ksplit_gr": 2}.get(cluster, -1)))
-    if cluster in ("round1", "ksplit_gr"):
+    # cluster=True: the K-split cluster scan (csrc/observe_ksplit.hip; default form: forward GRU split by output columns, flag
+    # hand-offs); "ksplit_r1": forward GRU split along K as well; "ksplit_gr": that form with granule hand-offs; "round1":
+    # observe_cluster.hip's form; False: one workgroup per tile (observe.hip)
+    cabi.check(cabi.lib.bd_observe_cluster_set_ksplit({"round1": 0, "ksplit_r1": 1, "ksplit_gr": 2}.get(cluster, -1)))
+    if cluster in ("round1", "ksplit_r1", "ksplit_gr"):
         cluster = True
     d, seed, hp, full, g, P, batch, noise, eng = _setup(name, cluster)
     if d.pixel:

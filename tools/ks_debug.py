@@ -7,7 +7,7 @@ d = getattr(synth, name)
 P, batch, noise = synth.make_params(d, 0), synth.make_batch(d, 0), synth.make_noise(d, 0)
 dev = lambda x: torch.as_tensor(x).cuda().contiguous()
 outs = {}
-for mode in (2, 1, 0):
+for mode in (3, 1, 0):
     cabi.check(cabi.lib.bd_observe_cluster_set_ksplit(mode))
     eng = DreamerEngine(d, None, "cuda", params=P)
     T, B, N = d.T, d.B, d.N
@@ -17,7 +17,7 @@ for mode in (2, 1, 0):
                                torch.zeros(B, d.Be, device="cuda"), torch.zeros(B, d.S, device="cuda"), T, B)
     torch.cuda.synchronize()
     outs[mode] = (feat.cpu().numpy().reshape(T, B, -1).copy(), qm.cpu().numpy().copy(), {k: eng._buf[k].cpu().numpy().copy() for k in ("sv_x", "sv_gates", "sv_q", "sv_s")})
-for m in (2, 1):
+for m in (3, 1):
     f1, f0 = outs[m][0], outs[0][0]
     print(f"== mode {m} vs round-1 form")
     print("feat diff per t:", [round(float(np.abs(f1[t] - f0[t]).max()), 5) for t in range(d.T)])

@@ -41,6 +41,11 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cat_pmc_fetch -- python3 $R/bench.py $C --steps 3 --warmup 1 $B > $OUT/cat_pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/cat_pmc_write -- python3 $R/bench.py $C --steps 3 --warmup 1 $B > $OUT/cat_pmc_write.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/cat_pmc_sq -- python3 $R/bench.py $C --steps 3 --warmup 1 $B > $OUT/cat_pmc_sq.log 2>&1 || exit 1
+# the same latents on state observations: counters only (the kernels differ in their row counts' neighbours, not in code)
+C2="--categorical state"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/catstate_pmc_fetch -- python3 $R/bench.py $C2 --steps 3 --warmup 1 $B > $OUT/catstate_pmc_fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/catstate_pmc_write -- python3 $R/bench.py $C2 --steps 3 --warmup 1 $B > $OUT/catstate_pmc_write.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/catstate_pmc_sq -- python3 $R/bench.py $C2 --steps 3 --warmup 1 $B > $OUT/catstate_pmc_sq.log 2>&1 || exit 1
 cd $R
 echo CAT_PROFILE_OK
 fi

@@ -179,6 +179,13 @@ if os.path.exists(os.path.join(src, "cat_bench.json")):
     readme.write(f"Bench line (un-profiled, {cb['steps']} steps): **{cb['value']:.0f} {cb['unit']}**, {cb['ms_per_step']:.3f} ms/step")
     if os.path.exists(os.path.join(src, "cat_state_bench.json")):
         sb = json.loads(open(os.path.join(src, "cat_state_bench.json")).read().strip().splitlines()[-1])
+        if os.path.isdir(os.path.join(src, "catstate_pmc_fetch")):       # counters of the state-observation run
+            straffic = traffic_of(pmc("catstate_pmc_fetch"), pmc("catstate_pmc_write"), pmc("catstate_pmc_sq"), names)
+            json.dump(straffic, open(os.path.join(dst, f"{tag}_catstate_traffic.json"), "w"), indent=1)
+            sdom = sb["roofline"]["kernel"]
+            if sdom in straffic:
+                sb["roofline"]["traffic"] = straffic[sdom]["hbm_bytes_per_launch"]
+                sb["roofline"]["traffic_source"] = f"{tag}_catstate_traffic.json"
         json.dump(sb, open(os.path.join(dst, f"{tag}_cat_state_bench.json"), "w"))
         readme.write(f"; the same latents on state observations (`--categorical state`): {sb['value']:.0f}, {sb['ms_per_step']:.3f} ms/step")
     readme.write(".\n\n")
