@@ -17,6 +17,8 @@
 //   F7  s' = mean + (softplus(raw) + min_std) eps          every member, elementwise
 // Backward, mirrored:  (dm, draw) -> dQ_c (N-split, local) -> dh partial (RS) -> gate gradients of block c ->
 // (DX, DH) partials (RS) -> dE_c, carry_c (the belief-gradient carry stays with its member) -> ds partial (all-reduce).
+// (The DEFAULT forward is observe_kfwd_ns_kernel further down: it splits the GRU by output columns and needs two hand-offs
+// per step; the form described here stays selectable and is what the backward mirrors.)
 // Three hand-offs per step and direction instead of one, each a few KB per member pair; per member and step 4 + 13 + 4
 // (forward) weight fragments of 1 KiB feed 300 MFMAs -- all register-resident, so a phase is: LDS read, MFMAs,
 // write-through stores, flag.  Hand-off protocol, flags, sticky error word: bd_cluster.h.  Reductions run in member order:
@@ -667,36 +669,26 @@ __global__ __launch_bounds__(kThreads) void observe_kfwd_ns_kernel(bd_observe_fw
         // (no phase A: this step's masked state / action fragments were written by the step before)
         BD_KSTAMP(1);
         // ---- F1: x, blocks wave and wave + 8 -> fragment tiles in LDS ----
-        // Branch-free: both blocks' MFMA chains in ONE basic block so that they interleave (absent blocks and absent K blocks
-        // carry zero weights; their operand reads are clamped to a valid fragment so that 0 x value stays finite).
+        // (12 dependent MFMAs per block at S = 30, A = 1: 0.4k cycles of issue each, two waves per SIMD.  A branch-free form
+        //  that pads to the compile-time maxima doubles the MFMAs and measured slower: 4.5k against 3.8k cycles.)
         {
             const floatx4* __restrict__ S4 = reinterpret_cast<const floatx4*>(sf) + lane;
             const floatx4* __restrict__ A4 = reinterpret_cast<const floatx4*>(af) + lane;
-            floatx4 sk[kKsMaxS], ak[kKsMaxA];
-#pragma unroll
-            for (int kb = 0; kb < kKsMaxS; ++kb) sk[kb] = S4[(kb < Kb_s ? kb : Kb_s - 1) * 64];
-#pragma unroll
-            for (int kb = 0; kb < kKsMaxA; ++kb) ak[kb] = A4[(kb < Kb_a ? kb : Kb_a - 1) * 64];
-            floatx4 acc0 = be4x[0], acc1 = be4x[1];
-#pragma unroll
-            for (int kb = 0; kb < kKsMaxS; ++kb) {
-                acc0 = mfmaT(we_s[0][kb], sk[kb], acc0);
-                acc1 = mfmaT(we_s[1][kb], sk[kb], acc1);
-            }
-#pragma unroll
-            for (int kb = 0; kb < kKsMaxA; ++kb) {
-                acc0 = mfmaT(we_a[0][kb], ak[kb], acc0);
-                acc1 = mfmaT(we_a[1][kb], ak[kb], acc1);
-            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int nbo = wave + kWaves * i;
-                const floatx4 acc = i ? acc1 : acc0;
-                floatx4 x4;
-                const int col0 = nbo * 16 + 4 * (lane >> 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) x4[j] = (rok && col0 + j < a.Be) ? elu(acc[j]) : 0.f;
                 if (nbo < Kb_h) {
+                    floatx4 acc = be4x[i];
+#pragma unroll
+                    for (int kb = 0; kb < kKsMaxS; ++kb)
+                        if (kb < Kb_s) acc = mfmaT(we_s[i][kb], S4[kb * 64], acc);
+#pragma unroll
+                    for (int kb = 0; kb < kKsMaxA; ++kb)
+                        if (kb < Kb_a) acc = mfmaT(we_a[i][kb], A4[kb * 64], acc);
+                    floatx4 x4;
+                    const int col0 = nbo * 16 + 4 * (lane >> 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x4[j] = (rok && col0 + j < a.Be) ? elu(acc[j]) : 0.f;
                     XF4[nbo * 64 + lane] = x4;
                     if (nbo == c && rok && a.sv_x) ks_put4(a.sv_x + (tb + grow) * a.Be + fcol0, x4, nbe);
                 }
