@@ -17,6 +17,8 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 $B > $OUT/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 $B > $OUT/pmc_write.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --steps 3 --warmup 1 $B > $OUT/pmc_sq.log 2>&1 || exit 1
+# the same step on ONE stream (BD_PIPELINE=0): every kernel alone on the GPU -- the un-contended durations
+BD_PIPELINE=0 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial_stats -- python3 $R/bench.py --steps 10 --warmup 2 $B > $OUT/serial_stats.log 2>&1 || exit 1
 cd $R
 echo MAIN_PROFILE_OK
 fi

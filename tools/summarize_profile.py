@@ -156,6 +156,15 @@ if os.path.exists(os.path.join(src, "pixel_bench.json")):
     readme.write(f"`wgrad_wide_kernel` by position in the step (kernel trace, us): {[round(m, 1) for m in means]} -> the decoder's "
                  f"grouped launch is position {dec}.\n\n")
     table(readme, ptraffic)
+# ------------------------------------------------------------------------------------------------ serial schedule: kernels alone
+ser = glob.glob(os.path.join(src, "serial_stats", "*", "*_kernel_stats.csv"))
+if ser:
+    shutil.copy(ser[0], os.path.join(dst, f"{tag}_serial_kernel_stats.csv"))
+    srow = list(csv.DictReader(open(ser[0])))
+    readme.write("\n## The same step on ONE stream (`BD_PIPELINE=0`): every kernel alone on the GPU\n\n"
+                 "Un-contended durations of the kernels of configs[1] (`rocprofv3 --kernel-trace --stats`, serial schedule); the table at "
+                 "the top has the same kernels under the three-stream pipeline.\n\n")
+    stats_table(readme, srow, 12)
 # ------------------------------------------------------------------------------------------------ categorical config
 if os.path.exists(os.path.join(src, "cat_bench.json")):
     cb = json.loads(open(os.path.join(src, "cat_bench.json")).read().strip().splitlines()[-1])
