@@ -339,8 +339,13 @@ __device__ __forceinline__ floatx4 tall_bias(const float* __restrict__ bias, int
     const int col0 = nb * 16 + 4 * (lane >> 4);
     floatx4 b = floatx4{0.f, 0.f, 0.f, 0.f};
     if (bias != nullptr && col0 < N) {
+        if (col0 + 4 <= N) {
+            __builtin_memcpy(&b, bias + col0, 16);      // one global_load_dwordx4 (4-byte aligned address)
+        } else {                                        // (the scans take any width)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b[r] = bias[col0 + r];
+            for (int r = 0; r < 4; ++r)
+                if (col0 + r < N) b[r] = bias[col0 + r];
+        }
     }
     return b;
 }
@@ -561,6 +566,12 @@ template <int NSEG, class Epi>
 __device__ __forceinline__ void tile_linear_seg(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N,
                                                 Epi&& epi, float* __restrict__ scratch = nullptr, int sb = -1) {
     tile_linear_g<1, NSEG>(seg, bias, N, [&](int, int nb, floatx4 acc) { epi(nb, acc); }, scratch, sb);
+}
+// the same with TRANSPOSED accumulators (linear_sweep<TR>): epi(nb, acc) gets out[row = lane & 15][nb*16 + 4*(lane>>4) + r]
+template <int NSEG, class Epi>
+__device__ __forceinline__ void tile_linear_seg_tr(const Seg (&seg)[NSEG], const float* __restrict__ bias, int N, Epi&& epi,
+                                                   int sb = -1) {
+    tile_linear_pre<1, NSEG, true>(seg, bias, N, NoPre{}, [&](int, int nb, floatx4 acc, NoPreVal) { epi(nb, acc); }, nullptr, sb);
 }
 
 // ---- tall workgroups: RT row tiles, balanced (row tile, column block) pairs, epilogue deferred -----------------

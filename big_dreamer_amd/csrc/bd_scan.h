@@ -76,6 +76,37 @@ struct HiddenEpi {
     }
 };
 
+// The same epilogue for TRANSPOSED accumulators (tile_linear_seg_tr): the lane's four values are four consecutive columns
+// of ONE row -- its 16 bytes of the next layer's fragment tile and 16 contiguous bytes of the row-major save: one
+// ds_write_b128 and one global_store_dwordx4 instead of four of each with four address computations.  In a scan the
+// epilogue of one wave competes for issue slots with the MFMA stream of the other wave of its SIMD (DESIGN: how a SIMD
+// shares its issue slot), so instruction count is what it costs.  Any width: a lane whose four columns straddle the edge
+// stores them one by one.
+struct HiddenEpiTR {
+    float* dst;
+    float* save;
+    size_t tn;
+    int width, rows, row0, lane;
+    __device__ __forceinline__ void operator()(int nb, floatx4 acc) const {
+        const int row = lane & 15, col0 = nb * 16 + 4 * (lane >> 4);
+        const bool rok = row0 + row < rows;
+        floatx4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (rok && col0 + r < width) ? elu(acc[r]) : 0.f;
+        reinterpret_cast<floatx4*>(dst)[nb * 64 + lane] = v;
+        if (save && rok && col0 < width) {
+            float* __restrict__ s = save + (tn + row0 + row) * width + col0;
+            if (col0 + 4 <= width) {
+                __builtin_memcpy(s, &v, 16);          // (4-byte aligned address: one global_store_dwordx4)
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col0 + r < width) s[r] = v[r];
+            }
+        }
+    }
+};
+
 // "gradient w.r.t. a hidden ELU output" epilogue: multiply by ELU' (from the saved output), keep in LDS for the
 // next contraction (dst may be null) and store for bd_wgrad (out may be null).
 struct DpreEpi {

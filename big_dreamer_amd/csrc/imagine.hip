@@ -75,14 +75,14 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         const int lane = tid & 63, wave = bd_wave(tid);
         // hidden layer epilogue: ELU -> LDS fragment (+ optional save)
         auto hidden_epi = [&](float* dst, float* save, size_t tn_, int width) {
-            return HiddenEpi{dst, save, tn_, width, a.N, row0, lane};
+            return HiddenEpiTR{dst, save, tn_, width, a.N, row0, lane};
         };
         BD_STAMP(0);
         BD_KARGS_FRESH(ap);
         // ---- actor hidden layers ----
         {
             const Seg segs[2] = {{h_cur, a.w_a0h, d.Kb_h}, {sf, a.w_a0s, d.Kb_s}};
-            tile_linear_seg<2>(segs, a.b_a[0], a.Hd, hidden_epi(bufA, a.sv_actor, tn, a.Hd));
+            tile_linear_seg_tr<2>(segs, a.b_a[0], a.Hd, hidden_epi(bufA, a.sv_actor, tn, a.Hd));
         }
         BD_STAMP(1);
         lds_barrier();
@@ -93,8 +93,8 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
             float* dst = bufB;
             for (int l = 1; l < 4; ++l) {
                 const Seg segs[1] = {{src, a.w_a[l - 1], d.Kb_hd}};
-                tile_linear_seg<1>(segs, a.b_a[l], a.Hd,
-                                      hidden_epi(dst, a.sv_actor ? a.sv_actor + l * act_stride : nullptr, tn, a.Hd), nullptr,
+                tile_linear_seg_tr<1>(segs, a.b_a[l], a.Hd,
+                                      hidden_epi(dst, a.sv_actor ? a.sv_actor + l * act_stride : nullptr, tn, a.Hd),
                                       (t == 3 && l == 2) ? 32 : -1);
                 BD_DSTAMP((t == 3 && l == 2) ? 32 : -1, 4);
                 lds_barrier();
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         // ---- embed ----
         {
             const Seg segs[2] = {{sf, a.w_embed_s, d.Kb_s}, {af, a.w_embed_a, d.Kb_a}};
-            tile_linear_seg<2>(segs, a.b_embed, a.Be, hidden_epi(xf, a.sv_x, tn, a.Be));
+            tile_linear_seg_tr<2>(segs, a.b_embed, a.Be, hidden_epi(xf, a.sv_x, tn, a.Be));
         }
         BD_STAMP(7);
         lds_barrier();
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kThreads) void imagine_fwd_kernel(bd_imagine_fwd_ar
         // ---- prior ----
         {
             const Seg segs[1] = {{h_nxt, a.w_p1, d.Kb_h}};
-            tile_linear_seg<1>(segs, a.b_p1, a.Hd, hidden_epi(bufA, a.sv_p, tn, a.Hd));
+            tile_linear_seg_tr<1>(segs, a.b_p1, a.Hd, hidden_epi(bufA, a.sv_p, tn, a.Hd));
         }
         BD_STAMP(11);
         lds_barrier();
