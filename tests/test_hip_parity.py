@@ -174,10 +174,14 @@ def test_train_steps_vs_oracle_and_golden(name, cluster, monkeypatch):
 
 
 @pytest.mark.parametrize("dims", [synth.Dims(B=5, L=4, H=4, Be=40, S=10, Hd=32, E=64, A=17, O=6),      # HumanoidStandup's action width
-                                  synth.Dims(B=18, L=3, H=3, Be=200, S=30, Hd=200, E=1024, A=17, O=3)])
+                                  synth.Dims(B=18, L=3, H=3, Be=200, S=30, Hd=200, E=1024, A=17, O=3),
+                                  # widths that are NOT multiples of 4: lanes whose four consecutive columns straddle the edge
+                                  # of a layer (transposed-accumulator epilogues, the K-split scan's row accessors)
+                                  synth.Dims(B=5, L=4, H=4, Be=42, S=10, Hd=30, E=64, A=3, O=6),
+                                  synth.Dims(B=20, L=3, H=3, Be=46, S=9, Hd=35, E=50, A=2, O=5)])
 def test_wide_action_vectors_vs_oracle(dims):
     """A = 17 (configs[2-3]) needs two K blocks for the action operand and two column blocks for the actor's mean / std
-    heads; the golden cases stop at A = 3.  Two train steps against the oracle."""
+    heads; the golden cases stop at A = 3.  Also: ragged layer widths.  Two train steps against the oracle."""
     from big_dreamer_amd.engine import DreamerEngine
     from oracle import dreamer_oracle as O
     d = dims
