@@ -363,6 +363,10 @@ class DreamerEngine:
         self.red_ws_bh = torch.zeros(int(lib.bd_reduce_ws_floats()), dtype=torch.float32, device=self.dev)
         self._buf: Dict[str, torch.Tensor] = {}
         # cluster variant of the observe scan (several CUs per 16-row tile): on unless BD_OBS_CLUSTER=0
+        # steps the host may run ahead of the GPU before train_step waits (0: no limit): two keep the launch queues fed and stay
+        # far below the depth at which the HIP runtime stalls the host to retire commands in bulk (5-6 steps of configs[1])
+        self.host_ahead = int(os.environ.get("BD_HOST_AHEAD", "2"))
+        self._bh_hist: List["torch.cuda.Event"] = []
         self.use_obs_cluster = os.environ.get("BD_OBS_CLUSTER", "1") != "0"
         self._obs_ws: Optional[torch.Tensor] = None
         self._obs_err_off: Optional[int] = None
@@ -1242,6 +1246,15 @@ class DreamerEngine:
             self._behaviour_phase(feat, nz, obs.shape[0] - 1, B, self.red_ws_bh, par)
             self._ev_bh_done[par] = torch.cuda.Event()
             self._ev_bh_done[par].record(s_bh)
+        # Host throttle.  Enqueueing a step takes ~1.1 ms of host time against ~2.8 ms on the GPU, so a caller that does not
+        # read the logs gets further ahead with every step; at ~8-10 steps (500-600 launches in flight) the HIP runtime
+        # blocks the host for 7-15 ms while it retires a whole batch of commands, and the streams run dry around each of
+        # those drains (3.7-4.0 ms steps, tools/step_trace.py).  Waiting here for the behaviour phase of `host_ahead` steps
+        # ago keeps the lead small and constant instead: no drains, every step at the steady-state rate from the fifth on.
+        if self.host_ahead > 0:
+            self._bh_hist.append(self._ev_bh_done[par])
+            if len(self._bh_hist) > self.host_ahead:
+                self._bh_hist.pop(0).synchronize()
         return self._finish_step(rec, sync_logs)
 
     def _finish_step(self, rec: Optional[_LogRecord], sync_logs):
