@@ -216,19 +216,12 @@ def run_workload(d, pixel, args, rank, world, dev, dist_on, steps, warmup, timer
             dist.barrier()
         torch.cuda.synchronize()
 
-    import gc
-    nogc = os.environ.get("BD_BENCH_GC", "1") == "0"
-    if nogc:
-        gc.collect()
-        gc.disable()
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    if nogc:
-        gc.enable()
     log(f"timed {steps} steps in {dt * 1e3:.1f} ms")
     logs = eng.logs()
     if dist_on:
