@@ -272,6 +272,17 @@ class DreamerEngine:
         assert self.dev.type == "cuda", "the HIP path needs a GPU (there is no CPU fallback)"
         self.world_size = world_size
         self.pg = process_group
+        # One RCCL communicator per optimiser (+ the caller's for the KL scalar) unless the caller brought its own.  All
+        # collectives of ONE communicator run in issue order on its internal stream, so the critic's all-reduce of step k -- off
+        # the critical path, at the end of a low-priority phase -- sat in front of the KL / world-model collectives of step k + 1
+        # whenever the critic phase ran late, and dynamics learning stalled behind it: the one-rank rehearsal read 4.3 or
+        # 3.6 ms/step instead of 2.9 depending on how HIP had mapped the streams to hardware queues (tools/r03_dp_rehearsal.sh).
+        # Issuing the actor / critic updates one host step late (below) fixes the ORDER of issue, separate communicators remove
+        # the coupling.  Collective: every rank builds its engine at the same point.  BD_PHASE_GROUPS=0: one communicator.
+        rehearsal = os.environ.get("BD_FORCE_DP", "0") == "1" and torch.distributed.is_initialized()
+        if (phase_groups is None and (world_size > 1 or rehearsal) and os.environ.get("BD_PHASE_GROUPS", "1") != "0"
+                and torch.distributed.get_backend(process_group) == "nccl"):
+            phase_groups = DataParallel.make_phase_groups("nccl")
         self.dp = DataParallel(world_size, torch.distributed.get_rank(process_group) if world_size > 1 else 0,
                                process_group, phase_groups)
         d = dims
