@@ -18,6 +18,9 @@ import os
 import sys
 import time
 
+# (before torch is imported: the HIP runtime reads it when it initialises; big_dreamer_amd/__init__.py has the measurements)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 import torch
 

@@ -285,6 +285,16 @@ class DreamerEngine:
             phase_groups = DataParallel.make_phase_groups("nccl")
         self.dp = DataParallel(world_size, torch.distributed.get_rank(process_group) if world_size > 1 else 0,
                                process_group, phase_groups)
+        if (world_size > 1 or rehearsal) and torch.distributed.get_backend(process_group) == "nccl":
+            # A process group created without `device_id` builds its communicators (and their internal streams) at the first
+            # collective -- which would be in the middle of the first train step, AFTER the engine's streams exist; created
+            # in that order the rehearsal ran 3.64 instead of 2.86 ms/step once the process had more than four hardware
+            # queues.  One tiny all-reduce per communicator here puts them first in every case.
+            self.dp.force = self.dp.force or rehearsal
+            tiny = torch.zeros(4, dtype=torch.float32, device=self.dev)
+            for g in (None, "model", "actor", "critic"):
+                self.dp.allreduce_sum_(tiny, g)
+            torch.cuda.synchronize(self.dev)
         d = dims
         shapes = param_shapes(d)
         # pixel mode: the conv stacks run on this library's gather-GEMM kernels (csrc/conv.hip, conv_stack.py) and their
@@ -346,9 +356,15 @@ class DreamerEngine:
         self._ev_cr_done: List[Optional[torch.cuda.Event]] = [None, None]
         # data-parallel: actor / critic optimiser steps (their all-reduces) are issued one host step late, see
         # _optimizer_step_or_defer; BD_DEFER_OPT=1 forces the same order on one GPU (tests)
-        self.defer_opt = world_size > 1 or os.environ.get("BD_DEFER_OPT", "0") == "1"
+        # (needed only where the three optimisers share ONE communicator: with one communicator each -- the default, above --
+        # the all-reduces cannot queue behind one another and the updates are issued where the serial schedule has them; held
+        # back, the actor's update of step k would wait for the host to queue all of dynamics learning k+1 first: +2 ms per
+        # step in the rehearsal of the pixel configuration)
+        shared_comm = not all(g in self.dp.groups for g in ("model", "actor", "critic"))
+        self.defer_opt = (world_size > 1 and shared_comm) or os.environ.get("BD_DEFER_OPT", "0") == "1"
         if os.environ.get("BD_FORCE_DP", "0") == "1" and torch.distributed.is_initialized():
-            self.dp.force = self.defer_opt = True      # single-rank rehearsal of the data-parallel schedule
+            self.dp.force = True                       # single-rank rehearsal of the data-parallel schedule
+            self.defer_opt = shared_comm or os.environ.get("BD_DEFER_OPT", "0") == "1"
         if (world_size > 1 or self.dp.force) and torch.cuda.current_stream(self.dev) == torch.cuda.default_stream(self.dev):
             # The legacy null stream synchronises implicitly with every BLOCKING stream of the process, and RCCL's is
             # one: with collectives in flight, each replay gather / stream hand-over the caller issues on the null

@@ -12,10 +12,12 @@ import random
 import sys
 import time
 
-import numpy as np
-import torch
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import big_dreamer_amd  # noqa: E402,F401  (first: sets the HIP runtime's queue count before HIP initialises)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
 from big_dreamer_amd.config import load_config  # noqa: E402
 
 
@@ -27,9 +29,10 @@ def my_app(argv):
     random.seed(params["seed"] + rank)
     if params["algorithm"] not in ("planet", "dreamer", "dreamerV2"):     # as src/main.py:73-81
         raise NotImplementedError(f'algorithm {params["algorithm"]} is not yet implemented.')
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-    if world > 1:
-        torch.distributed.init_process_group("nccl")
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    if world > 1:      # (device_id: the communicator is built now, before the engine's streams -- DESIGN.md section 6)
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_stream(torch.cuda.Stream())        # stay off the legacy null stream
     from big_dreamer_amd.dreamer import Dreamer, DreamerV2
     from big_dreamer_amd.planet import Planet

@@ -10,10 +10,8 @@ print("GPU_MAX_HW_QUEUES =", os.environ.get("GPU_MAX_HW_QUEUES"))
 import torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 os.environ["BD_FORCE_DP"] = "1"
-if os.environ.get("RCCL_HIGH", "1") == "1":
-    opts = dist.ProcessGroupNCCL.Options()
-    opts.is_high_priority_stream = True
-    dist.init_process_group("nccl", rank=0, world_size=1, pg_options=opts)
+if os.environ.get("REH_DEVICE_ID", "0") == "1":      # eager communicator, as bench.py creates it
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 else:
     dist.init_process_group("nccl", rank=0, world_size=1)
 from big_dreamer_amd import synth
@@ -21,6 +19,8 @@ from big_dreamer_amd.engine import DreamerEngine
 from big_dreamer_amd.memory import ExperienceReplay
 d, dev = synth.CONFIG2, torch.device("cuda", 0)
 torch.cuda.set_device(dev)
+if os.environ.get("REH_OWN_STREAM", "0") == "1":     # the caller on a stream of its own, as bench.py
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
 eng = DreamerEngine(d, None, dev, params=synth.make_params(d, 0), world_size=1)      # (BD_PHASE_GROUPS=0: one communicator)
 rep = synth.make_replay(d, rows=5000, seed=0)
 buf = ExperienceReplay(5000, d.A, 5, False, d.O, dev)
