@@ -282,7 +282,7 @@ class DreamerEngine:
         rehearsal = os.environ.get("BD_FORCE_DP", "0") == "1" and torch.distributed.is_initialized()
         if (phase_groups is None and (world_size > 1 or rehearsal) and os.environ.get("BD_PHASE_GROUPS", "1") != "0"
                 and torch.distributed.get_backend(process_group) == "nccl"):
-            phase_groups = DataParallel.make_phase_groups("nccl")
+            phase_groups = DataParallel.make_phase_groups("nccl", process_group)
         self.dp = DataParallel(world_size, torch.distributed.get_rank(process_group) if world_size > 1 else 0,
                                process_group, phase_groups)
         if (world_size > 1 or rehearsal) and torch.distributed.get_backend(process_group) == "nccl":

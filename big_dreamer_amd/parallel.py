@@ -33,9 +33,11 @@ class DataParallel:
         self.force = False
 
     @staticmethod
-    def make_phase_groups(backend: Optional[str] = None) -> dict:
-        """Three process groups over all ranks (collective: every rank calls it, once)."""
-        return {k: torch.distributed.new_group(backend=backend) for k in ("model", "actor", "critic")}
+    def make_phase_groups(backend: Optional[str] = None, parent=None) -> dict:
+        """Three process groups over the ranks of `parent` (default: all ranks).  Collective: every rank of the default group
+        calls it, once, in the same order (torch.distributed.new_group)."""
+        ranks = torch.distributed.get_process_group_ranks(parent) if parent is not None else None
+        return {k: torch.distributed.new_group(ranks=ranks, backend=backend) for k in ("model", "actor", "critic")}
 
     # ---- scaling --------------------------------------------------------------------------------------
     def mean_grad_scale(self, local_count: int) -> float:
